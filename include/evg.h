@@ -1,0 +1,174 @@
+/*
+ * evg.h -- C-ABI of the MI355X-native batched Everglades environment (libevg.so).
+ *
+ * This is the drop-in boundary for ONE hot path of jlehett/everglades-ai-wargame: the
+ * everglades-server turn loop plus gym_everglades step()/reset(), vectorised over N
+ * independent two-player DemoMap games whose state lives struct-of-arrays in HBM.
+ * The reference has no FFI of its own -- its Gym class *is* the boundary
+ * (gym-everglades/gym_everglades/envs/everglades_env.py:13-173).  Each entry point below
+ * cites the reference code it replaces; the Python binding a maintainer would add is in
+ * INTEGRATION.md and shipped as everglades-ai-wargame_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer marked "device" is a HIP device pointer owned by the
+ *     caller (e.g. torch.Tensor.data_ptr()); the handle owns only the persistent game state.
+ *   - all calls return 0 on success or a negative evg_status; evg_last_error() gives the text
+ *     (thread-local).  No C++ exception crosses the ABI.
+ *   - step/reset/random_actions ENQUEUE on the caller's hipStream_t (`stream`, may be NULL for the
+ *     default stream) and return without synchronising.  One handle per device; not thread-safe.
+ *   - there is NO CPU fallback: evg_create fails with EVG_ERR_NO_DEVICE when no gfx950 device
+ *     is usable.
+ *   - env e of this handle has the global id env_id_base + e; random streams are keyed by the
+ *     global id, so results do not depend on how envs are sharded over GPUs.
+ */
+#ifndef EVG_H
+#define EVG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVG_ABI_VERSION 1
+
+/* Fixed dimensions of the reference environment (everglades_env.py:17-22). */
+#define EVG_NUM_PLAYERS 2
+#define EVG_NUM_GROUPS 12      /* num_groups            */
+#define EVG_NUM_NODES 11       /* num_nodes (IDs 1..11) */
+#define EVG_NUM_UNITS 100      /* num_units per player  */
+#define EVG_NUM_ACTIONS 7      /* num_actions_per_turn  */
+#define EVG_OBS_LEN 105        /* 1 + 4*11 + 5*12 (everglades_env.py:158-171) */
+#define EVG_MAX_UNIT_TYPES 4
+#define EVG_MAX_GROUP_SIZE 12
+#define EVG_MAX_SCORE 3700     /* everglades_env.py:11 */
+
+typedef enum evg_status {
+    EVG_OK = 0,
+    EVG_ERR_INVALID = -1,      /* bad argument / table out of the supported domain */
+    EVG_ERR_NO_DEVICE = -2,    /* no usable HIP device (there is no CPU path)        */
+    EVG_ERR_HIP = -3,          /* a HIP runtime call failed                         */
+    EVG_ERR_ALLOC = -4
+} evg_status;
+
+typedef enum evg_obs_dtype { EVG_OBS_F32 = 0, EVG_OBS_F64 = 1, EVG_OBS_I16 = 2 } evg_obs_dtype;
+
+/* game status (server.py:284-288) */
+enum { EVG_IN_PROGRESS = 0, EVG_TIME_EXPIRED = 1, EVG_BASE_CAPTURE = 2, EVG_ANNIHILATION = 3 };
+/* winner_out values; the harness rule evaluate.py:155-160 applied to the terminal rewards */
+enum { EVG_WINNER_NONE = -1, EVG_WINNER_P0 = 0, EVG_WINNER_P1 = 1, EVG_WINNER_TIE = 2 };
+/* node_resource bits (DemoMap.json "Resource") */
+enum { EVG_RES_DEFENSE = 1, EVG_RES_OBSERVE = 2 };
+
+/*
+ * Flattened constant tables: what server.py:40-131 parses out of config/DemoMap.json and
+ * config/UnitDefinitions.json plus the army of everglades_env.py:145-156.  Node arrays are
+ * indexed by node ID (1..11; entry 0 unused).  Domain checked by evg_create:
+ *   distances 0 (not connected) or 1..7; control_points 1..511; defense >= 0;
+ *   unit damage/speed/control/cost >= 1 and small (<= 15), unit health >= 1;
+ *   group sizes even, 2..12, summing to <= 100 per player.
+ */
+typedef struct evg_tables {
+    int32_t node_dist[EVG_NUM_NODES + 1][EVG_NUM_NODES + 1];
+    int32_t node_control_points[EVG_NUM_NODES + 1];
+    double  node_defense[EVG_NUM_NODES + 1];
+    int32_t node_resource[EVG_NUM_NODES + 1];
+    int32_t node_team_start[EVG_NUM_NODES + 1];        /* -1, 0 or 1                         */
+    int32_t p1_node_map[EVG_NUM_NODES + 1];            /* server.py:89                       */
+    int32_t num_unit_types;
+    int32_t unit_health[EVG_MAX_UNIT_TYPES];           /* "armor" in the damage equation      */
+    int32_t unit_damage[EVG_MAX_UNIT_TYPES];
+    int32_t unit_speed[EVG_MAX_UNIT_TYPES];
+    int32_t unit_control[EVG_MAX_UNIT_TYPES];
+    int32_t unit_cost[EVG_MAX_UNIT_TYPES];
+    int32_t group_type[EVG_NUM_PLAYERS][EVG_NUM_GROUPS];  /* unit type id of each group        */
+    int32_t group_size[EVG_NUM_PLAYERS][EVG_NUM_GROUPS];  /* units per group at reset          */
+    int32_t max_turns;                                    /* 150 (server.py:321)               */
+} evg_tables;
+
+typedef struct evg_config {
+    uint32_t struct_size;      /* = sizeof(evg_config); ABI guard            */
+    uint32_t abi_version;      /* = EVG_ABI_VERSION                          */
+    int32_t  num_envs;         /* N >= 1                                     */
+    int32_t  device_id;        /* HIP device ordinal                         */
+    uint64_t seed;             /* Philox key                                 */
+    uint64_t env_id_base;      /* global id of env 0 of this handle          */
+    int32_t  obs_dtype;        /* evg_obs_dtype of obs_out buffers           */
+    int32_t  auto_reset;       /* 1: an env that finishes in step() is reset in the same launch and
+                                  obs_out holds the first observation of its next episode           */
+    evg_tables tables;
+} evg_config;
+
+typedef struct evg_handle evg_handle;
+
+/* Fills `t` with the DemoMap / UnitDefinitions / default-army tables. */
+void evg_default_tables(evg_tables* t);
+
+/* Replaces EvergladesGame.__init__/board_init/unitTypes_init (server.py:14-131): tables are parsed
+ * once by the host and copied to the device; state for N envs is allocated (uninitialised until
+ * the first evg_reset). */
+int evg_create(const evg_config* cfg, evg_handle** out);
+void evg_destroy(evg_handle* h);
+
+/* Replaces EvergladesEnv.reset (everglades_env.py:75-116) -> game_init (server.py:133-209) ->
+ * _build_observations (everglades_env.py:158-171).
+ *   mask    device uint8[N] or NULL (= all): envs with mask != 0 start a new episode
+ *   obs_out device [N][2][105] of cfg.obs_dtype or NULL; written for the envs that were reset */
+int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream);
+
+/* Replaces EvergladesEnv.step (everglades_env.py:32-73) -> EvergladesGame.game_turn
+ * (server.py:211-279: orders, combat :503, movement :656, capture :708, game_end :281) ->
+ * board_state/player_state (:382-501).  build_knowledge_output (:769-907) mutates nothing and is
+ * not reproduced.
+ *   actions    device int32 [N][2][7][2]  (group id, node id in the player's own numbering);
+ *              out-of-domain ids are invalid orders, never undefined behaviour
+ *   obs_out    device [N][2][105] of cfg.obs_dtype
+ *   reward_out device float [N][2]   (everglades_env.py:37-61)
+ *   done_out   device uint8 [N]
+ *   winner_out device int8  [N]  or NULL
+ *   scores_out device int32 [N][2] or NULL  (server.py:291-317)
+ *   status_out device uint8 [N]  or NULL  (server.py:284-288)
+ * Without auto_reset a finished env is frozen: further steps leave it unchanged and repeat its
+ * terminal outputs. */
+int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward_out, uint8_t* done_out,
+             int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream);
+
+/* Input generator for the benchmark configs: the on-device equivalent of
+ * agents/State_Machine/random_actions.py:38-46 for every env and both players, keyed by
+ * (seed, env id, episode, turn, player).  actions_out: device int32 [N][2][7][2]. */
+int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream);
+
+/* Canonical state exchange (host order; used by parity tests and to load golden positions).
+ * All pointers are HOST pointers; the call synchronises.  Any pointer may be NULL.
+ *   groups int32 [N][2][12][8]: location, travel_destination (-1 none), distance_remaining, ready,
+ *                               moving, destroyed, count, arrival stamp      (definitions.py:35-64)
+ *   nodes  int32 [N][11][2]   : controlState, controlledBy                   (definitions.py:16-17)
+ *   health double[N][2][100]  : unitHealth of the groups back to back         (definitions.py:62)
+ *   env    int32 [N][4]       : current_turn, status, episode, reserved
+ */
+int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health, int32_t* env);
+int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, const double* health,
+                  const int32_t* env);
+
+/* Per-env results of the most recently finished episode, and running totals (device -> host copy,
+ * synchronises).  Any pointer may be NULL.
+ *   returns float [N][2]  sum of rewards over the episode
+ *   length  int32 [N]     turns played
+ *   winner  int8  [N]     EVG_WINNER_* (NONE if the env has not finished an episode yet)
+ *   totals  int64 [4]     episodes finished, p0 wins, p1 wins, ties (this handle, since create)
+ */
+int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* winner, int64_t* totals);
+/* Device pointers to the same per-env arrays (returns float[N][2], length int32[N], winner int8[N]),
+ * for the multi-GPU gather of episode returns without a host round trip. */
+int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner);
+
+int evg_num_envs(const evg_handle* h);
+/* bytes of persistent device state per env (for the roofline accounting in DESIGN.md) */
+int evg_state_bytes_per_env(const evg_handle* h);
+const char* evg_last_error(void);
+int evg_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVG_H */

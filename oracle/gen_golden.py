@@ -1,0 +1,447 @@
+#!/usr/bin/env python3
+"""Golden-fixture generator (TEST INFRASTRUCTURE; runs ONLY in the build container).
+
+Imports the unmodified reference from /root/reference, plants the build's counter-based
+RNG (oracle/rng_spec.py) in place of the module-global `np.random.randint` the reference
+draws from (server.py:205,338,562), plays seeded games under several action policies and
+writes inputs + expected outputs as small .npz files under tests/golden/.  Nothing of the
+reference itself is written: the fixtures hold action streams, observations, rewards,
+scores, status and state snapshots (numbers), which is what the parity tests replay
+through the C oracle and through the HIP path.
+
+    python oracle/gen_golden.py            # regenerate everything (about 2 minutes)
+
+Loader recipe: SURVEY.md Appendix B (np.int alias; a stub `gym` package so the real
+gym_everglades/envs/everglades_env.py imports unmodified).
+"""
+import os
+import sys
+import types
+import time
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("EVG_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+import rng_spec  # noqa: E402
+
+NG, NN, NU, NA = 12, 11, 100, 7
+P1MAP = [0, 11, 8, 9, 10, 5, 6, 7, 2, 3, 4, 1]
+
+
+# ----------------------------------------------------------------------------------------------
+# reference loading
+# ----------------------------------------------------------------------------------------------
+def _install_fake_gym():
+    """Minimal stand-in for the absent `gym` package: just enough names for the reference's
+    everglades_env.py / everglades_renderer.py / __init__.py to import.  No behaviour."""
+    gym = types.ModuleType("gym")
+
+    class Env(object):
+        pass
+
+    class _Space(object):
+        def __init__(self, *a, **k):
+            self.args, self.kwargs = a, k
+            low = k.get("low")
+            self.shape = None if low is None else np.asarray(low).shape
+
+    gym.Env = Env
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Tuple = spaces.Discrete = spaces.Box = _Space
+    error = types.ModuleType("gym.error")
+    utils = types.ModuleType("gym.utils")
+    seeding = types.ModuleType("gym.utils.seeding")
+    utils.seeding = seeding
+    envs = types.ModuleType("gym.envs")
+    cc = types.ModuleType("gym.envs.classic_control")
+    rendering = types.ModuleType("gym.envs.classic_control.rendering")
+    cc.rendering = rendering
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda **k: None
+    envs.classic_control, envs.registration = cc, reg
+    gym.spaces, gym.error, gym.utils, gym.envs = spaces, error, utils, envs
+    for name, mod in [("gym", gym), ("gym.spaces", spaces), ("gym.error", error), ("gym.utils", utils),
+                      ("gym.utils.seeding", seeding), ("gym.envs", envs), ("gym.envs.classic_control", cc),
+                      ("gym.envs.classic_control.rendering", rendering), ("gym.envs.registration", reg)]:
+        sys.modules[name] = mod
+
+
+class _RandomProxy(object):
+    """Replaces `np.random` inside everglades_server.server: randint(n) becomes the keyed draw."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def randint(self, n):
+        fr = sys._getframe(1)
+        if fr.f_code.co_name != "combat":
+            return 0  # the two focus draws (game_init / game_end) are unobservable
+        L = fr.f_locals
+        o = self._o
+        pid, i, j, counts = L["pid"], L["i"], L["j"], L["counts"]
+        ordinal = int(sum(int(c) for c in counts[pid][:i])) + int(j)
+        o.draws += 1
+        return rng_spec.combat_draw(o.seed, o.env_id, o.episode, L["self"].current_turn, L["node"].ID,
+                                    pid, ordinal, int(n))
+
+    def __getattr__(self, k):
+        return getattr(np.random, k)
+
+
+class _NpProxy(object):
+    def __init__(self):
+        self.seed = self.env_id = self.episode = 0
+        self.draws = 0
+        self.random = _RandomProxy(self)
+
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+
+def load_reference():
+    np.int = int  # removed from numpy>=1.24; the reference uses it (server.py:55,79,430,471)
+    _install_fake_gym()
+    sys.path.insert(0, os.path.join(REF, "everglades-server"))
+    sys.path.insert(0, os.path.join(REF, "gym-everglades"))
+    from everglades_server import server
+    from gym_everglades.envs.everglades_env import EvergladesEnv
+    proxy = _NpProxy()
+    server.np = proxy
+    return server, EvergladesEnv, proxy
+
+
+# ----------------------------------------------------------------------------------------------
+# state extraction from the reference's objects
+# ----------------------------------------------------------------------------------------------
+GF_LOC, GF_DEST, GF_DIST, GF_READY, GF_MOVING, GF_DESTROYED, GF_COUNT, GF_STAMP = range(8)
+
+
+class Tracker(object):
+    """Follows one reference game and dumps the canonical state (tests/README of the layout:
+    groups[2][12][8] = loc,dest,dist,ready,moving,destroyed,count,stamp; nodes[11][2] =
+    controlState,controlledBy; health[2][100]; rank[2][12] = index in its node's list or -1)."""
+
+    def __init__(self, game):
+        self.game = game
+        self.stamp = np.zeros((2, NG), np.int16)
+        self.prev_loc = np.array([[g.location for g in game.players[p].groups] for p in (0, 1)])
+
+    def after_turn(self):
+        g = self.game
+        for p in (0, 1):
+            for k, grp in enumerate(g.players[p].groups):
+                if grp.location != self.prev_loc[p, k]:
+                    self.stamp[p, k] = g.current_turn
+                    self.prev_loc[p, k] = grp.location
+
+    def snapshot(self):
+        g = self.game
+        groups = np.zeros((2, NG, 8), np.int16)
+        health = np.zeros((2, NU), np.float64)
+        rank = -np.ones((2, NG), np.int8)
+        for p in (0, 1):
+            off = 0
+            for k, grp in enumerate(g.players[p].groups):
+                u = grp.units[0]
+                groups[p, k] = [grp.location, grp.travel_destination, grp.distance_remaining, int(grp.ready),
+                                int(grp.moving), int(grp.destroyed), u.count, self.stamp[p, k]]
+                n = len(u.unitHealth)
+                health[p, off:off + n] = u.unitHealth
+                off += n
+        nodes = np.zeros((NN, 2), np.int16)
+        for node in g.evgMap.nodes:
+            nodes[node.ID - 1] = [node.controlState, node.controlledBy]
+            for p in (0, 1):
+                lst = list(node.groups[p])
+                for r, gid in enumerate(lst):
+                    rank[p, gid] = r
+                # invariant behind the SoA encoding: list order == (arrival stamp, gid) order
+                keys = [(int(self.stamp[p, gid]), gid) for gid in lst]
+                assert keys == sorted(keys), ("list order != stamp order", node.ID, p, lst, keys)
+        return groups, nodes, health, rank
+
+
+# ----------------------------------------------------------------------------------------------
+# action policies (inputs only; every stream is stored in the fixture)
+# ----------------------------------------------------------------------------------------------
+ADJ = {1: {2: 6, 4: 6}, 2: {1: 6, 3: 4, 5: 4}, 3: {2: 4, 4: 4, 5: 6, 6: 3, 7: 6}, 4: {1: 6, 3: 4, 7: 4},
+       5: {2: 4, 3: 6, 8: 4, 9: 6}, 6: {3: 3, 9: 3}, 7: {3: 6, 4: 4, 9: 6, 10: 4}, 8: {5: 4, 9: 4, 11: 6},
+       9: {5: 6, 6: 3, 7: 6, 8: 4, 10: 4}, 10: {7: 4, 9: 4, 11: 6}, 11: {8: 6, 10: 6}}
+
+
+def _next_hop(src, dst):
+    import heapq
+    dist, prev, pq = {src: 0}, {}, [(0, src)]
+    while pq:
+        d, u = heapq.heappop(pq)
+        if d > dist.get(u, 1e9):
+            continue
+        for v, w in ADJ[u].items():
+            if d + w < dist.get(v, 1e9):
+                dist[v], prev[v] = d + w, u
+                heapq.heappush(pq, (d + w, v))
+    if src == dst:
+        return src
+    v = dst
+    while prev[v] != src:
+        v = prev[v]
+    return v
+
+
+HOP = {(s, d): _next_hop(s, d) for s in ADJ for d in ADJ}
+
+
+def pol_random(ctx, p, obs):
+    rows = rng_spec.random_action_rows(ctx["seed"], ctx["env_id"], ctx["episode"], int(obs[0]), p)
+    return np.array(rows, dtype=np.float64)
+
+
+def _march(obs, target, rows, rot):
+    loc = obs[45::5].astype(int)
+    mov = obs[48::5].astype(int)
+    alive = obs[49::5].astype(int)
+    out = []
+    for k in range(NG):
+        g = (k + rot) % NG
+        if not mov[g] and alive[g] > 0 and loc[g] != target:
+            out.append((g, HOP[(int(loc[g]), target)]))
+    out = out[:rows]
+    while len(out) < rows:
+        out.append((0, 0))
+    return np.array(out, dtype=np.float64)
+
+
+def pol_rush(ctx, p, obs):
+    return _march(obs, 11, 7, int(obs[0]))
+
+
+def pol_brawl(ctx, p, obs):
+    return _march(obs, 6, 12, 0)  # 12 rows submitted, only the first 7 are honoured (server.py:227)
+
+
+def pol_wild(ctx, p, obs):
+    r = ctx["nprng"]
+    rows = int(r.integers(5, 10))
+    a = np.zeros((rows, 2))
+    a[:, 0] = r.integers(0, 12, rows)
+    a[:, 1] = r.integers(0, 12, rows)
+    if r.random() < 0.5:  # duplicate group ids
+        a[r.integers(0, rows), 0] = a[0, 0]
+    frac = r.random((rows, 2)) * 0.999
+    a = a + frac * (r.random((rows, 2)) < 0.3)  # fractional floats truncate (server.py:232)
+    return a
+
+
+def pol_zero(ctx, p, obs):
+    return np.zeros((7, 2))
+
+
+POLICIES = {"random": (pol_random, pol_random), "wild": (pol_wild, pol_wild), "rush": (pol_rush, pol_rush),
+            "brawl": (pol_brawl, pol_brawl), "brawl_v_random": (pol_brawl, pol_random),
+            "rush_v_random": (pol_rush, pol_random)}
+
+
+def canon_actions(a):
+    """What the server does to a player's array before using it: first 7 rows, astype(int)
+    (server.py:227,232); shorter arrays are padded with the always-invalid order (0,0)."""
+    a = np.asarray(a)[:7].astype(int)
+    out = np.zeros((7, 2), np.int8)
+    out[:len(a)] = a
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# game driver
+# ----------------------------------------------------------------------------------------------
+class Runner(object):
+    def __init__(self):
+        self.server, self.EnvCls, self.proxy = load_reference()
+        self.cfg = dict(config_dir=os.path.join(REF, "config") + "/", map_file=os.path.join(REF, "config", "DemoMap.json"),
+                        unit_file=os.path.join(REF, "config", "UnitDefinitions.json"), output_dir="/tmp/evg_unused/",
+                        pnames={0: "a", 1: "b"}, debug=False)
+        self.env = self.EnvCls()
+        self.EnvCls.render = lambda self_, mode="human": None
+        import gym_everglades.envs.everglades_env as ee
+
+        class _NoRenderer(object):
+            def __init__(self, game):
+                pass
+
+            def render(self, mode="human"):
+                pass
+
+            def close(self):
+                pass
+
+        ee.EvergladesRenderer = _NoRenderer
+
+    def reset(self, seed, env_id, episode):
+        self.proxy.seed, self.proxy.env_id, self.proxy.episode = seed, env_id, episode
+        obs = self.env.reset(players={0: None, 1: None}, **self.cfg)
+        return obs
+
+    def play(self, policy, seed, env_id, episode=0, full=True, pre_edit=None, script=None, max_turns=400):
+        """Returns a dict of per-turn arrays.  `script`: optional list of (a0, a1) overriding the policy."""
+        obs = self.reset(seed, env_id, episode)
+        game = self.env.game
+        if pre_edit is not None:
+            pre_edit(game)
+            obs = self.env._build_observations()
+        tr = Tracker(game)
+        ctx = [dict(seed=seed, env_id=env_id, episode=episode, nprng=np.random.default_rng([seed, env_id, p]))
+               for p in (0, 1)]
+        pols = POLICIES[policy] if policy in POLICIES else (pol_zero, pol_zero)
+        rec = dict(obs=[np.stack([obs[0], obs[1]])], actions=[], raw0=[], raw1=[], reward=[], done=[], scores=[],
+                   status=[], groups=[], nodes=[], health=[], rank=[])
+        g, n, h, r = tr.snapshot()
+        rec["groups"].append(g), rec["nodes"].append(n), rec["health"].append(h), rec["rank"].append(r)
+        done, t = 0, 0
+        while not done and t < max_turns:
+            if script is not None and t < len(script):
+                a0, a1 = (np.asarray(x, dtype=np.float64) for x in script[t])
+            else:
+                a0, a1 = pols[0](ctx[0], 0, obs[0]), pols[1](ctx[1], 1, obs[1])
+            # scores/status are locals of step(); recover them by wrapping game_turn for this call
+            box = {}
+            orig = game.game_turn
+
+            def wrapped(actions, _o=orig, _b=box):
+                s, st = _o(actions)
+                _b["scores"], _b["status"] = (int(s[0]), int(s[1])), int(st)
+                return s, st
+
+            game.game_turn = wrapped
+            obs, reward, done, info = self.env.step({0: a0, 1: a1})
+            game.game_turn = orig
+            tr.after_turn()
+            t += 1
+            rec["actions"].append(np.stack([canon_actions(a0), canon_actions(a1)]))
+            rec["obs"].append(np.stack([obs[0], obs[1]]))
+            rec["reward"].append([float(reward[0]), float(reward[1])])
+            rec["done"].append(int(done))
+            rec["scores"].append(box["scores"])
+            rec["status"].append(box["status"])
+            g, n, h, r = tr.snapshot()
+            rec["groups"].append(g), rec["nodes"].append(n), rec["health"].append(h), rec["rank"].append(r)
+        out = dict(length=t)
+        for k in ("obs", "actions", "reward", "done", "scores", "status", "groups", "nodes", "health", "rank"):
+            out[k] = np.array(rec[k])
+        assert np.all(out["obs"] == np.round(out["obs"])) and np.abs(out["obs"]).max() <= 500
+        return out
+
+
+def pack(games, metas, tmax=150):
+    """Stack variable-length games (padded to tmax turns)."""
+    G = len(games)
+    d = dict(
+        policy=np.array([m["policy"] for m in metas]), seed=np.array([m["seed"] for m in metas], np.uint64),
+        env_id=np.array([m["env_id"] for m in metas], np.uint32), episode=np.array([m["episode"] for m in metas], np.uint32),
+        length=np.array([g["length"] for g in games], np.int32),
+        obs=np.zeros((G, tmax + 1, 2, 105), np.int16), actions=np.zeros((G, tmax, 2, 7, 2), np.int8),
+        reward=np.zeros((G, tmax, 2), np.float64), done=np.zeros((G, tmax), np.uint8),
+        scores=np.zeros((G, tmax, 2), np.int32), status=np.zeros((G, tmax), np.uint8),
+        groups=np.zeros((G, tmax + 1, 2, NG, 8), np.int16), nodes=np.zeros((G, tmax + 1, NN, 2), np.int16),
+        health=np.zeros((G, tmax + 1, 2, NU), np.float64), rank=np.zeros((G, tmax + 1, 2, NG), np.int8))
+    for i, g in enumerate(games):
+        T = g["length"]
+        d["obs"][i, :T + 1] = g["obs"]
+        for k in ("actions", "reward", "done", "scores", "status"):
+            d[k][i, :T] = g[k]
+        for k in ("groups", "nodes", "health", "rank"):
+            d[k][i, :T + 1] = g[k]
+    return d
+
+
+# ----------------------------------------------------------------------------------------------
+def kat_script():
+    """deterministic no-combat trajectory."""
+    z = np.zeros((7, 2))
+    a0 = z.copy(); a0[0] = [1, 2]; a0[1] = [0, 4]
+    a1 = z.copy(); a1[0] = [1, 2]
+    return [(a0, a1)] + [(z, z)] * 11
+
+
+def edit_annihilation(game):
+    """Hand-made position (server objects edited in place) that ends by Annihilation (status 3,
+    server.py:324-325): each side is reduced to one 1-health unit, both at node 6, so the two
+    simultaneous hits kill both armies on the next turn."""
+    for p in (0, 1):
+        for k, grp in enumerate(game.players[p].groups):
+            u = grp.units[0]
+            if k == 1:  # a striker group (damage 2)
+                u.unitHealth[:] = 0.0
+                u.unitHealth[3] = 5.0
+                u.count = 1
+                old = [n for n in game.evgMap.nodes if n.ID == grp.location][0]
+                old.groups[p].remove(k)
+                grp.location = 6
+                [n for n in game.evgMap.nodes if n.ID == 6][0].groups[p].append(k)
+            else:
+                u.unitHealth[:] = 0.0
+                u.count = 0
+                grp.destroyed = True
+                old = [n for n in game.evgMap.nodes if n.ID == grp.location][0]
+                old.groups[p].remove(k)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    t0 = time.time()
+    R = Runner()
+    stats = {}
+
+    # 1. full-state trajectories, several policies
+    plan = [("random", 6), ("wild", 6), ("rush", 4), ("brawl", 4), ("brawl_v_random", 4), ("rush_v_random", 4)]
+    for pi, (pol, cnt) in enumerate(plan):
+        games, metas = [], []
+        for i in range(cnt):
+            seed, env_id, episode = 1000 + 17 * pi + i, 7 * i + pi, i % 3
+            g = R.play(pol, seed, env_id, episode)
+            games.append(g)
+            metas.append(dict(policy=pol, seed=seed, env_id=env_id, episode=episode))
+        d = pack(games, metas)
+        np.savez_compressed(os.path.join(OUT, "traj_%s.npz" % pol), **d)
+        stats[pol] = (d["length"].tolist(), [int(s[l - 1]) for s, l in zip(d["status"], d["length"])], R.proxy.draws)
+        print(pol, stats[pol], "%.1fs" % (time.time() - t0), flush=True)
+
+    # 2. deterministic KAT (no RNG involved)
+    g = R.play("zero", 1, 0, 0, script=kat_script(), max_turns=12)
+    np.savez_compressed(os.path.join(OUT, "kat_nocombat.npz"), **pack([g], [dict(policy="kat", seed=1, env_id=0, episode=0)], tmax=12))
+
+    # 3. edited position -> Annihilation
+    g = R.play("zero", 5, 3, 0, pre_edit=edit_annihilation, max_turns=3)
+    assert g["status"][g["length"] - 1] == 3, g["status"]
+    np.savez_compressed(os.path.join(OUT, "edit_annihilation.npz"),
+                        **pack([g], [dict(policy="edit", seed=5, env_id=3, episode=0)], tmax=3))
+
+    # 4. bulk random-vs-random: outcomes + per-turn checksums only
+    B = 120
+    seedB = 20261003
+    res = dict(seed=np.uint64(seedB), env_id=np.arange(B, dtype=np.uint32), length=np.zeros(B, np.int32),
+               scores=np.zeros((B, 2), np.int32), status=np.zeros(B, np.uint8), reward=np.zeros((B, 2)),
+               obs_sum=np.zeros((B, 151, 2), np.int32), health_final=np.zeros((B, 2, NU)),
+               alive_final=np.zeros((B, 2), np.int32))
+    for i in range(B):
+        g = R.play("random", seedB, i, 0)
+        T = g["length"]
+        res["length"][i] = T
+        res["scores"][i] = g["scores"][T - 1]
+        res["status"][i] = g["status"][T - 1]
+        res["reward"][i] = g["reward"][T - 1]
+        res["obs_sum"][i, :T + 1] = g["obs"].astype(np.int64).sum(axis=2)
+        res["health_final"][i] = g["health"][T]
+        res["alive_final"][i] = (g["health"][T] > 0).sum(axis=1)
+        if i % 20 == 19:
+            print("bulk", i + 1, "%.1fs" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(OUT, "bulk_random.npz"), **res)
+    w0 = int((res["scores"][:, 0] > res["scores"][:, 1]).sum())
+    w1 = int((res["scores"][:, 1] > res["scores"][:, 0]).sum())
+    print("bulk wins p0/p1/tie:", w0, w1, B - w0 - w1)
+    print("done in %.1fs" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+"""CPU tests: pin the C oracle (oracle/evg_oracle.c) against fixtures generated from the imported,
+unmodified reference (oracle/gen_golden.py).  Bit-exact for every integer and for float64 health;
+rewards within 1e-12 (same float64 arithmetic)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_initial_state, TRAJ_FILES
+
+
+def replay(om, d, g, check_state=True):
+    seed, env_id, episode = int(d["seed"][g]), int(d["env_id"][g]), int(d["episode"][g])
+    T = int(d["length"][g])
+    o = om.Oracle(1, seed=seed, env_id_base=env_id)
+    obs = o.reset()
+    if episode or not np.array_equal(d["health"][g, 0], o.get_state()["health"][0]):
+        # fixture starts from another episode index or from an edited position
+        o.set_state(*golden_initial_state(d, g))
+        obs = o.observe()
+    assert np.array_equal(obs[0], d["obs"][g, 0].astype(np.float64)), "reset obs"
+    for t in range(T):
+        obs, reward, done, info = o.step(d["actions"][g, t][None].astype(np.int32))
+        assert np.array_equal(obs[0], d["obs"][g, t + 1].astype(np.float64)), ("obs", g, t)
+        assert np.array_equal(info["scores"][0], d["scores"][g, t]), ("scores", g, t)
+        assert info["status"][0] == d["status"][g, t], ("status", g, t)
+        assert done[0] == d["done"][g, t]
+        assert np.allclose(reward[0], d["reward"][g, t], rtol=0, atol=1e-12), ("reward", g, t)
+        if check_state:
+            s = o.get_state()
+            assert np.array_equal(s["health"][0], d["health"][g, t + 1]), ("health bits", g, t)
+            assert np.array_equal(s["groups"][0], d["groups"][g, t + 1]), ("groups", g, t)
+            assert np.array_equal(s["nodes"][0], d["nodes"][g, t + 1]), ("nodes", g, t)
+            assert np.array_equal(s["rank"][0], d["rank"][g, t + 1]), ("node list order", g, t)
+    return o
+
+
+@pytest.mark.parametrize("fname", TRAJ_FILES)
+def test_trajectories_bit_exact(oracle_mod, fname):
+    d = load_golden(fname)
+    for g in range(len(d["length"])):
+        replay(oracle_mod, d, g)
+
+
+def test_kat_values_from_survey(oracle_mod):
+    """The hand-checked numbers of SURVEY.md section 8c for the no-combat trajectory."""
+    d = load_golden("kat_nocombat.npz")
+    sc = d["scores"][0]
+    assert [tuple(sc[t]) for t in range(8)] == [(1100, 1100)] * 3 + [(1108, 1108), (1116, 1116), (1124, 1124),
+                                                                     (1148, 1132), (1172, 1140)]
+    p1 = d["obs"][0, 8, 1, :45].tolist()
+    assert p1 == [8, 0, 0, -500, 0, 0, 1, -40, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 40, 8,
+                  0, 0, 0, 0, 1, 0, 32, 8, 0, 0, 500, 84]
+    o = replay(oracle_mod, d, 0)
+    assert o.get_state()["env"][0, 0] == 12
+
+
+def test_reset_observation(oracle_mod):
+    """everglades_env.py reset observation."""
+    o = oracle_mod.Oracle(3, seed=9)
+    obs = o.reset()
+    p0 = obs[0, 0]
+    assert p0[0] == 0 and p0[1:5].tolist() == [0, 0, 500, 0] and p0[41:45].tolist() == [0, 0, -500, 100]
+    assert p0[45:50].tolist() == [1, 1, 100, 0, 8] and p0[50:55].tolist() == [1, 2, 100, 0, 8]
+    assert p0[55:60].tolist() == [1, 0, 100, 0, 8] and p0[100:105].tolist() == [1, 0, 100, 0, 12]
+    p1 = obs[0, 1]
+    assert p1[3] == -500 and p1[43] == 500 and p1[44] == 100 and p1[45] == 1
+    assert np.array_equal(obs[0], obs[2])
+
+
+def test_annihilation_edit(oracle_mod):
+    d = load_golden("edit_annihilation.npz")
+    replay(oracle_mod, d, 0)
+    assert d["status"][0, 0] == 3 and d["done"][0, 0] == 1
+    assert d["reward"][0, 0].tolist() == [0.0, 0.0] or d["scores"][0, 0, 0] != d["scores"][0, 0, 1]
+
+
+def test_bulk_random_outcomes(oracle_mod):
+    """120 random-vs-random games (actions from the on-device generator contract): final scores, status,
+    per-turn observation checksums and final float64 health equal the reference's."""
+    d = load_golden("bulk_random.npz")
+    B = len(d["length"])
+    o = oracle_mod.Oracle(B, seed=int(d["seed"]), env_id_base=0)
+    obs = o.reset()
+    assert np.array_equal(obs.sum(axis=2).astype(np.int32), d["obs_sum"][:, 0])
+    final_scores = np.zeros((B, 2), np.int32)
+    final_status = np.zeros(B, np.uint8)
+    for t in range(150):
+        a = o.random_actions()
+        obs, reward, done, info = o.step(a)
+        live = d["length"] > t
+        assert np.array_equal(obs.sum(axis=2).astype(np.int32)[live], d["obs_sum"][live, t + 1]), t
+        ending = d["length"] == t + 1
+        final_scores[ending] = info["scores"][ending]
+        final_status[ending] = info["status"][ending]
+        assert np.array_equal(done.astype(bool), d["length"] <= t + 1)
+    assert np.array_equal(final_scores, d["scores"]) and np.array_equal(final_status, d["status"])
+    s = o.get_state()
+    assert np.array_equal(s["health"], d["health_final"])
+    st = o.episode_stats()
+    w0 = int((d["scores"][:, 0] > d["scores"][:, 1]).sum())
+    w1 = int((d["scores"][:, 1] > d["scores"][:, 0]).sum())
+    assert st["totals"].tolist() == [B, w0, w1, B - w0 - w1]
+
+
+def test_rng_contract(oracle_mod):
+    import rng_spec
+    assert oracle_mod.philox((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert oracle_mod.philox((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == \
+        (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+    r = np.random.default_rng(0)
+    for _ in range(300):
+        seed = int(r.integers(0, 2 ** 63)) * 2 + 1
+        env_id, ep = int(r.integers(0, 2 ** 32)), int(r.integers(0, 2 ** 32))
+        turn, node, pl, ordn, n = int(r.integers(1, 151)), int(r.integers(1, 12)), int(r.integers(0, 2)), int(r.integers(0, 100)), int(r.integers(1, 101))
+        assert oracle_mod.combat_draw(seed, env_id, ep, turn, node, pl, ordn, n) == \
+            rng_spec.combat_draw(seed, env_id, ep, turn, node, pl, ordn, n)
+    o = oracle_mod.Oracle(4, seed=77, env_id_base=1000)
+    o.reset()
+    a = o.random_actions()
+    for e in range(4):
+        for p in range(2):
+            assert a[e, p].tolist() == [list(x) for x in rng_spec.random_action_rows(77, 1000 + e, 0, 0, p)]
+            assert len(set(a[e, p, :, 0])) == 7 and len(set(a[e, p, :, 1])) == 7 and a[e, p, :, 1].min() >= 1
+
+
+def test_np_sum_model(oracle_mod):
+    """np.sum on 8- and 12-element float64 vectors == the 8-accumulator pairwise model (server.py:481)."""
+    r = np.random.default_rng(1)
+    for n in (8, 12, 4, 2):
+        for _ in range(20000):
+            a = np.where(r.random(n) < 0.3, 0.0, r.random(n) * 100.0)
+            assert np.sum(a) == oracle_mod.np_sum(a)
