@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec at 65 536 concurrent DemoMap games per MI355X, random vs random.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E]
+
+One "step" = one pass of the hot path over one batch: on-device random action generation for both
+players of every env (the input generator, agents/State_Machine/random_actions.py) + the fused
+env-step kernel (game_turn + observations + rewards, auto-reset on).  Inputs and outputs stay in HBM.
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); environments shard by
+contiguous global id (weak scaling: 65 536 per GPU) and the only collective is the gather of episode
+results at episode boundaries (RCCL all-gather over xGMI).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per env-step = read + write of the 1 780 B state
+# (health f64[2][100] 1 600 + groups 144 + nodes 33 + turn/status 2) + actions 112 + obs f32 840 + 18.
+ALGO_BYTES_PER_ENV_STEP = 4530
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(seed, budget_s=12.0):
+    """The CPU oracle (C port of the reference's turn loop, oracle/evg_oracle.c) timed on this box's host
+    cores with OpenMP over envs: same workload (random vs random incl. action generation and observations,
+    auto-reset), bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ctypes as C
+    import numpy as np
+    import oracle as om
+    L = om.lib()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    L.evo_set_num_threads(cores)
+    n = 8192
+    o = om.Oracle(n, seed=seed, auto_reset=True)
+    o.reset()
+    a = np.zeros((n, 2, 7, 2), np.int32)
+    obs = np.zeros((n, 2, 105), np.float64)
+    rew = np.zeros((n, 2), np.float64)
+    done = np.zeros(n, np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    for _ in range(10):          # warm-up (threads, page faults)
+        L.evo_random_actions(o.h, p(a)); L.evo_step(o.h, p(a), p(obs), p(rew), p(done), None, None, None)
+    o = om.Oracle(n, seed=seed, auto_reset=True)
+    o.reset()
+    t0, turns = time.perf_counter(), 0
+    while True:
+        for _ in range(50):
+            L.evo_random_actions(o.h, p(a)); L.evo_step(o.h, p(a), p(obs), p(rew), p(done), None, None, None)
+        turns += 50
+        dt = time.perf_counter() - t0
+        if (dt >= budget_s and turns % 150 == 0) or dt >= 2.5 * budget_s:
+            break
+    return dict(value=n * turns / dt, unit="env-steps/s", cores=cores, kind="port",
+                sample="%d envs x %d turns (random vs random, action generation + step + f64 observations, auto-reset), "
+                       "C oracle with OpenMP over envs; the Python reference itself runs 529-554 env-steps/s on one core "
+                       "(BASELINE.md, measured in the build container)" % (n, turns))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=450)
+    ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--envs", type=int, default=65536, help="concurrent games per GPU")
+    ap.add_argument("--seed", type=int, default=20261003)
+    ap.add_argument("--obs-dtype", default="float32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    import everglades_amd as evg
+
+    n_local = args.envs
+    total = n_local * world
+    first, cnt = evg.shard_range(total, world, rank)
+    assert cnt == n_local
+    env = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed, env_id_base=first, obs_dtype=args.obs_dtype, auto_reset=True)
+    env.reset()
+    stats_dev = env.episode_stats_device()
+    period = 150                                   # episode length of random vs random: gather at episode boundaries
+
+    def one_step():
+        env.step(env.random_actions())
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:                                  # warm the collective too
+        evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total)
+
+    # ---- timed region: exactly K steps
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    gathered = None
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        a = env.random_actions()
+        ev0[i].record()                            # same stream the kernels are launched on (torch's current stream)
+        env.step(a)
+        ev1[i].record()
+        if (args.warmup + i + 1) % period == 0:
+            gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    step_kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+
+    if rank == 0:
+        value = total * args.steps / dt
+        achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9
+        st = env.episode_stats()
+        out = {
+            "metric": "env-steps/sec at 65536 concurrent DemoMap games, 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32+f64", "data": "synthetic",
+            "config": {"workload": "%d concurrent DemoMap games per GPU, random_actions vs random_actions generated on device, "
+                                   "auto-reset, obs %s [N,2,105]" % (n_local, args.obs_dtype),
+                       "envs_per_gpu": n_local, "total_envs": total, "parallelism": "env-sharded x%d" % world,
+                       "episodes_finished_rank0": int(st["totals"][0]),
+                       "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
+                       "gathered_wins_all_ranks": list(gathered["wins"]) if gathered is not None else None},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms,
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.seed)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

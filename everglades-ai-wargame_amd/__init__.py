@@ -1,0 +1,22 @@
+"""MI355X-native batched Everglades environment.
+
+Drop-in for the turn loop of everglades-server and step()/reset() of gym_everglades
+(jlehett/everglades-ai-wargame): Python host code over a thin C-ABI (include/evg.h, libevg.so)
+whose kernels are hand-written HIP for gfx950.  Import as `everglades_amd` (alias module at the
+repository root; this directory's name is not a legal Python identifier).
+"""
+from . import _lib
+from ._lib import EvgError, load as load_library
+from .tables import default_tables, tables_from_json
+from .vec_env import EvergladesVecEnv
+from .env import EvergladesEnv, canonical_actions
+from .distributed import shard_range, gather_episode_results
+
+__all__ = ["EvergladesVecEnv", "EvergladesEnv", "EvgError", "load_library", "default_tables", "tables_from_json",
+           "canonical_actions", "shard_range", "gather_episode_results"]
+
+try:  # optional: same gym id as the reference (gym_everglades/__init__.py:3-6) when gym is installed
+    from gym.envs.registration import register as _register
+    _register(id="everglades-v0", entry_point="everglades_amd:EvergladesEnv")
+except Exception:
+    pass

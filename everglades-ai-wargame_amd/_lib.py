@@ -1,0 +1,90 @@
+"""ctypes binding of libevg.so (include/evg.h).  This is the whole FFI surface; no torch types cross it.
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C everglades-ai-wargame_amd/csrc`.
+There is no CPU fallback: a missing library or a missing gfx950 device raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libevg.so")
+
+NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105
+MAX_SCORE = 3700
+OBS_F32, OBS_F64, OBS_I16 = 0, 1, 2
+ABI_VERSION = 1
+
+EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_random_actions",
+           "evg_get_state", "evg_set_state", "evg_episode_stats", "evg_episode_stats_device", "evg_num_envs",
+           "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
+
+
+class EvgTables(C.Structure):
+    _fields_ = [
+        ("node_dist", (C.c_int32 * 12) * 12), ("node_control_points", C.c_int32 * 12),
+        ("node_defense", C.c_double * 12), ("node_resource", C.c_int32 * 12),
+        ("node_team_start", C.c_int32 * 12), ("p1_node_map", C.c_int32 * 12),
+        ("num_unit_types", C.c_int32), ("unit_health", C.c_int32 * 4), ("unit_damage", C.c_int32 * 4),
+        ("unit_speed", C.c_int32 * 4), ("unit_control", C.c_int32 * 4), ("unit_cost", C.c_int32 * 4),
+        ("group_type", (C.c_int32 * 12) * 2), ("group_size", (C.c_int32 * 12) * 2), ("max_turns", C.c_int32),
+    ]
+
+
+class EvgConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int32), ("device_id", C.c_int32),
+        ("seed", C.c_uint64), ("env_id_base", C.c_uint64), ("obs_dtype", C.c_int32), ("auto_reset", C.c_int32),
+        ("tables", EvgTables),
+    ]
+
+
+class EvgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libevg.so; fail loudly when it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EvgError("libevg.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C everglades-ai-wargame_amd/csrc`; this package has no CPU fallback" % LIB_PATH)
+    # libevg.so shares streams and device pointers with PyTorch, so both must run on ONE HIP runtime
+    # instance: import torch first, so that its libamdhip64.so.7 is the one already in the process when
+    # the loader resolves libevg's NEEDED entry of the same SONAME.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.evg_last_error.restype = C.c_char_p
+    L.evg_abi_version.restype = C.c_int
+    L.evg_default_tables.argtypes = [C.POINTER(EvgTables)]
+    L.evg_default_tables.restype = None
+    L.evg_create.argtypes = [C.POINTER(EvgConfig), C.POINTER(vp)]
+    L.evg_destroy.argtypes = [vp]
+    L.evg_destroy.restype = None
+    L.evg_reset.argtypes = [vp, vp, vp, vp]
+    L.evg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.evg_observe.argtypes = [vp, vp, vp]
+    L.evg_random_actions.argtypes = [vp, vp, vp]
+    L.evg_get_state.argtypes = [vp, vp, vp, vp, vp]
+    L.evg_set_state.argtypes = [vp, vp, vp, vp, vp]
+    L.evg_episode_stats.argtypes = [vp, vp, vp, vp, vp]
+    L.evg_episode_stats_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.evg_num_envs.argtypes = [vp]
+    L.evg_state_bytes_per_env.argtypes = [vp]
+    if L.evg_abi_version() != ABI_VERSION:
+        raise EvgError("libevg.so ABI version %d, binding expects %d" % (L.evg_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise EvgError("libevg error %d: %s" % (rc, load().evg_last_error().decode("utf-8", "replace")))

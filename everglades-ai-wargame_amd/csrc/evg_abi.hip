@@ -1,0 +1,432 @@
+// evg_abi.hip -- host side of the C-ABI declared in include/evg.h (libevg.so).
+// Owns the persistent device state of one handle, validates and flattens the constant tables,
+// and enqueues the kernels of evg_kernels.hip on the caller's stream.  No CPU execution path.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "evg_device.h"
+
+using namespace evg;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(EVG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));  \
+    } while (0)
+
+constexpr int kGroupSize[NG] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 12};   // everglades_env.py:145-156
+
+// numpy pairwise order for the cached int(avg health) (server.py:481,491); state import only
+double host_np_sum(const double* h, int n) {
+    double s = ((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7]));
+    for (int i = 8; i < n; ++i) s += h[i];
+    return s;
+}
+
+}  // namespace
+
+struct evg_handle {
+    evg_config cfg;
+    DevTables host_tables;
+    DevState S;
+    DevTables* d_tables = nullptr;
+    std::vector<void*> allocs;
+};
+
+template <typename Tp>
+static int dev_alloc(evg_handle* h, Tp** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(Tp));
+    if (e != hipSuccess) return fail(EVG_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(Tp), hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = reinterpret_cast<Tp*>(q);
+    return EVG_OK;
+}
+
+extern "C" {
+
+const char* evg_last_error(void) { return g_err; }
+int evg_abi_version(void) { return EVG_ABI_VERSION; }
+
+void evg_default_tables(evg_tables* t) {
+    memset(t, 0, sizeof(*t));
+    struct Edge { int a, b, d; };
+    // config/DemoMap.json:5-300 (each connection listed once; the JSON lists both directions)
+    static const Edge edges[] = {{1, 2, 6}, {1, 4, 6}, {2, 3, 4}, {2, 5, 4}, {3, 4, 4}, {3, 5, 6}, {3, 6, 3}, {3, 7, 6}, {4, 7, 4},
+                                 {5, 8, 4}, {5, 9, 6}, {6, 9, 3}, {7, 9, 6}, {7, 10, 4}, {8, 9, 4}, {8, 11, 6}, {9, 10, 4}, {10, 11, 6}};
+    for (const Edge& e : edges) t->node_dist[e.a][e.b] = t->node_dist[e.b][e.a] = e.d;
+    static const double defense[12] = {0, 1, 1.5, 1.75, 1.5, 1.75, 1.75, 1.75, 1.5, 1.75, 1.5, 1};
+    static const int p1map[12] = {0, 11, 8, 9, 10, 5, 6, 7, 2, 3, 4, 1};      // server.py:89
+    for (int n = 0; n <= NN; ++n) {
+        t->node_control_points[n] = (n == 1 || n == 11) ? 500 : 100;
+        t->node_defense[n] = defense[n];
+        t->node_team_start[n] = n == 1 ? 0 : (n == 11 ? 1 : -1);
+        t->p1_node_map[n] = p1map[n];
+    }
+    t->node_control_points[0] = 0;
+    t->node_resource[2] = t->node_resource[8] = EVG_RES_OBSERVE;
+    t->node_resource[4] = t->node_resource[10] = EVG_RES_DEFENSE;
+    // config/UnitDefinitions.json:4-27, ids by JSON order: tank 0, controller 1, striker 2
+    t->num_unit_types = 3;
+    static const int ud[3][5] = {{3, 1, 1, 1, 1}, {2, 1, 1, 2, 1}, {1, 2, 2, 1, 1}};   // health damage speed control cost
+    for (int u = 0; u < 3; ++u) {
+        t->unit_health[u] = ud[u][0]; t->unit_damage[u] = ud[u][1]; t->unit_speed[u] = ud[u][2];
+        t->unit_control[u] = ud[u][3]; t->unit_cost[u] = ud[u][4];
+    }
+    static const int cls[3] = {1, 2, 0};                                       // ['controller','striker','tank'][g % 3]
+    for (int p = 0; p < NP; ++p)
+        for (int g = 0; g < NG; ++g) { t->group_type[p][g] = cls[g % 3]; t->group_size[p][g] = kGroupSize[g]; }
+    t->max_turns = 150;
+}
+
+static int build_dev_tables(const evg_config* cfg, DevTables* D) {
+    const evg_tables& t = cfg->tables;
+    memset(D, 0, sizeof(*D));
+    if (t.num_unit_types < 1 || t.num_unit_types > EVG_MAX_UNIT_TYPES) return fail(EVG_ERR_INVALID, "num_unit_types out of range");
+    if (t.max_turns < 1 || t.max_turns > 255) return fail(EVG_ERR_INVALID, "max_turns must be in 1..255");
+    for (int u = 0; u < t.num_unit_types; ++u) {
+        if (t.unit_health[u] < 1 || t.unit_health[u] > 255 || t.unit_damage[u] < 1 || t.unit_damage[u] > 15 || t.unit_speed[u] < 1 ||
+            t.unit_speed[u] > 15 || t.unit_control[u] < 1 || t.unit_control[u] > 15 || t.unit_cost[u] < 1 || t.unit_cost[u] > 15)
+            return fail(EVG_ERR_INVALID, "unit type %d outside the supported domain", u);
+        D->damage_nib |= (uint32_t)t.unit_damage[u] << (4 * u);
+        D->armor_byte |= (uint32_t)t.unit_health[u] << (8 * u);
+        D->unit_speed[u] = t.unit_speed[u]; D->unit_control[u] = t.unit_control[u]; D->unit_cost[u] = t.unit_cost[u];
+    }
+    int start[2] = {-1, -1};
+    bool seen[12] = {false};
+    for (int n = 1; n <= NN; ++n) {
+        for (int m = 0; m <= NN; ++m) {
+            const int d = t.node_dist[n][m];
+            if (d < 0 || d > 7 || (m == 0 && d != 0) || (m == n && d != 0)) return fail(EVG_ERR_INVALID, "node_dist[%d][%d]=%d unsupported", n, m, d);
+            D->adj_row[n] |= (uint64_t)d << (4 * m);
+        }
+        if (t.node_control_points[n] < 1 || t.node_control_points[n] > 511) return fail(EVG_ERR_INVALID, "control points of node %d", n);
+        if (!(t.node_defense[n] >= 0.0)) return fail(EVG_ERR_INVALID, "defense of node %d", n);
+        const int ts = t.node_team_start[n];
+        if (ts < -1 || ts > 1) return fail(EVG_ERR_INVALID, "team start of node %d", n);
+        if (ts >= 0) { if (start[ts] != -1) return fail(EVG_ERR_INVALID, "two start nodes for player %d", ts); start[ts] = n; }
+        const int pm = t.p1_node_map[n];
+        if (pm < 1 || pm > NN || seen[pm]) return fail(EVG_ERR_INVALID, "p1_node_map is not a permutation of 1..11");
+        seen[pm] = true;
+        D->control_points[n] = t.node_control_points[n];
+        D->defense[n] = t.node_defense[n];
+        D->team_start[n] = ts;
+        D->resource[n] = t.node_resource[n];
+        D->p1map_nib |= (uint64_t)pm << (4 * n);
+    }
+    D->team_start[0] = -1;
+    if (t.p1_node_map[0] != 0) return fail(EVG_ERR_INVALID, "p1_node_map[0] must be 0");
+    if (start[0] < 0 || start[1] < 0 || start[0] == start[1]) return fail(EVG_ERR_INVALID, "each player needs its own start node");
+    int max_damage[2] = {0, 0};
+    for (int p = 0; p < NP; ++p)
+        for (int g = 0; g < NG; ++g) {
+            const int ty = t.group_type[p][g];
+            if (ty < 0 || ty >= t.num_unit_types) return fail(EVG_ERR_INVALID, "group_type[%d][%d]", p, g);
+            if (t.group_size[p][g] != kGroupSize[g])
+                return fail(EVG_ERR_INVALID, "group_size[%d][%d]=%d: this build fixes the army shape of everglades_env.py:145-156 (8 x 11 + 12)",
+                            p, g, t.group_size[p][g]);
+            D->group_type[p][g] = ty;
+            D->type_nib[p] |= (uint64_t)ty << (4 * g);
+            max_damage[p] += kGroupSize[g] * t.unit_damage[ty];
+        }
+    if (max_damage[0] > 255 || max_damage[1] > 255) return fail(EVG_ERR_INVALID, "total damage of an army must fit 8 bits");
+    D->max_turns = t.max_turns;
+
+    // state right after game_init: everyone at home (list order = gid order, stamp 0), turn-0 capture
+    for (int p = 0; p < NP; ++p)
+        for (int g = 0; g < NG; ++g) {
+            const uint32_t mask = (1u << kGroupSize[g]) - 1u;
+            D->init_grp[p * NG + g] = (uint32_t)start[p] | (mask << G_MASK_S) | (100u << G_AVG_S);
+        }
+    for (int n = 1; n <= NN; ++n) {
+        int cs = 0, cb = t.node_team_start[n];                 // definitions.py:16-17
+        for (int p = 0; p < NP; ++p)
+            if (start[p] == n) { cs = (p == 0 ? 1 : -1) * t.node_control_points[n]; cb = p; }   // server.py:744-745,763-765
+        D->init_node[n] = (uint32_t)(cs + 512) | ((uint32_t)(cb + 1) << 10);
+    }
+
+    // observation record + descriptors (kernel comment "fields")
+    int16_t f[REC_FIELDS];
+    memset(f, 0, sizeof(f));
+    for (int n = 1; n <= NN; ++n) {
+        f[n] = (int16_t)((int)(D->init_node[n] & 0x3FF) - 512);
+        f[11 + n] = (int16_t)(start[1] == n ? NU : 0);
+        f[22 + n] = (int16_t)(start[0] == n ? NU : 0);
+    }
+    for (int p = 0; p < NP; ++p)
+        for (int g = 0; g < NG; ++g) {
+            const int b = 34 + 4 * (p * NG + g);
+            f[b] = (int16_t)(p == 1 ? t.p1_node_map[start[p]] : start[p]);
+            f[b + 1] = 100; f[b + 2] = 0; f[b + 3] = (int16_t)kGroupSize[g];
+        }
+    for (int w = 0; w < REC_WORDS; ++w) D->reset_rec[w] = (uint32_t)(uint16_t)f[2 * w] | ((uint32_t)(uint16_t)f[2 * w + 1] << 16);
+
+    uint16_t desc1[2 * OBS];
+    for (int p = 0; p < NP; ++p) {
+        uint16_t* d = desc1 + p * OBS;
+        d[0] = 0;                                                                     // turn
+        for (int i = 1; i <= NN; ++i) {
+            const int n = p == 1 ? t.p1_node_map[i] : i;                              // server.py:437-439
+            d[1 + 4 * (i - 1) + 0] = (uint16_t)(0x8000 | ((t.node_resource[n] & EVG_RES_DEFENSE) ? 1 : 0));
+            d[1 + 4 * (i - 1) + 1] = (uint16_t)(0x8000 | ((t.node_resource[n] & EVG_RES_OBSERVE) ? 1 : 0));
+            d[1 + 4 * (i - 1) + 2] = (uint16_t)n;                                     // controlState, sign not mirrored
+            d[1 + 4 * (i - 1) + 3] = (uint16_t)(p == 0 ? 11 + n : 22 + n);            // opposing units listed at the node
+        }
+        for (int g = 0; g < NG; ++g) {
+            const int b = 34 + 4 * (p * NG + g);
+            uint16_t* o = d + 45 + 5 * g;
+            o[0] = (uint16_t)b;
+            o[1] = (uint16_t)(0x8000 | t.group_type[p][g]);
+            o[2] = (uint16_t)(b + 1); o[3] = (uint16_t)(b + 2); o[4] = (uint16_t)(b + 3);
+        }
+    }
+    const int U = cfg->obs_dtype == EVG_OBS_F64 ? 1 : (cfg->obs_dtype == EVG_OBS_F32 ? 2 : 4);
+    D->desc_unit_envs = U;
+    for (int u = 0; u < U; ++u)
+        for (int i = 0; i < 2 * OBS; ++i) {
+            const uint16_t d = desc1[i];
+            D->obs_desc[u * 2 * OBS + i] = (d & 0x8000) ? d : (uint16_t)(d | (u << 8));
+        }
+    for (int i = 0; i < 2 * OBS; ++i) {
+        const uint16_t d = desc1[i];
+        D->reset_obs[i] = (d & 0x8000) ? (int16_t)(d & 0x7FFF) : f[d & 0xFF];
+    }
+    return EVG_OK;
+}
+
+int evg_create(const evg_config* cfg, evg_handle** out) {
+    if (!cfg || !out) return fail(EVG_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(evg_config) || cfg->abi_version != EVG_ABI_VERSION)
+        return fail(EVG_ERR_INVALID, "evg_config size/version mismatch (got %u/%u, want %zu/%d)", cfg->struct_size, cfg->abi_version,
+                    sizeof(evg_config), EVG_ABI_VERSION);
+    if (cfg->num_envs < 1) return fail(EVG_ERR_INVALID, "num_envs must be >= 1");
+    if (cfg->obs_dtype < EVG_OBS_F32 || cfg->obs_dtype > EVG_OBS_I16) return fail(EVG_ERR_INVALID, "obs_dtype");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(EVG_ERR_NO_DEVICE, "no HIP device visible; libevg has no CPU path");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(EVG_ERR_NO_DEVICE, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(EVG_ERR_NO_DEVICE, "device %d is %s; libevg is built for gfx950 (MI355X) only", cfg->device_id, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(cfg->device_id));
+
+    evg_handle* h = new evg_handle();
+    h->cfg = *cfg;
+    int rc = build_dev_tables(cfg, &h->host_tables);
+    if (rc != EVG_OK) { delete h; return rc; }
+    const size_t N = (size_t)cfg->num_envs;
+    DevState& S = h->S;
+    memset(&S, 0, sizeof(S));
+    S.N = cfg->num_envs;
+    S.auto_reset = cfg->auto_reset ? 1 : 0;
+    S.seed_lo = (uint32_t)cfg->seed;
+    S.seed_hi = (uint32_t)(cfg->seed >> 32);
+    S.env_id_base = (uint32_t)cfg->env_id_base;
+    rc = dev_alloc(h, &S.grp, 24 * N);
+    if (!rc) rc = dev_alloc(h, &S.stamp, 6 * N);
+    if (!rc) rc = dev_alloc(h, &S.node, NN * N);
+    if (!rc) rc = dev_alloc(h, &S.env, N);
+    if (!rc) rc = dev_alloc(h, &S.episode, N);
+    if (!rc) rc = dev_alloc(h, &S.health, 2 * NU * N);
+    if (!rc) rc = dev_alloc(h, &S.ep_ret, 2 * N);
+    if (!rc) rc = dev_alloc(h, &S.fin_ret, 2 * N);
+    if (!rc) rc = dev_alloc(h, &S.fin_len, N);
+    if (!rc) rc = dev_alloc(h, &S.fin_win, N);
+    if (!rc) rc = dev_alloc(h, &S.totals, 4);
+    if (!rc) rc = dev_alloc(h, &h->d_tables, 1);
+    if (rc) { evg_destroy(h); return rc; }
+    S.T = h->d_tables;
+    hipError_t e = hipMemcpy(h->d_tables, &h->host_tables, sizeof(DevTables), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(S.episode, 0, N * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(S.fin_ret, 0, 2 * N * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(S.fin_len, 0, N * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(S.fin_win, 0xFF, N);
+    if (e == hipSuccess) e = hipMemset(S.totals, 0, 4 * sizeof(unsigned long long));
+    // every env starts in the game_init position; the episode counter is then set to -1 so that the
+    // first evg_reset opens episode 0
+    if (e == hipSuccess && launch_reset(S, nullptr, nullptr, cfg->obs_dtype, nullptr) != 0) e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemset(S.episode, 0xFF, N * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { evg_destroy(h); return fail(EVG_ERR_HIP, "state initialisation failed: %s", hipGetErrorString(e)); }
+    *out = h;
+    return EVG_OK;
+}
+
+void evg_destroy(evg_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+int evg_num_envs(const evg_handle* h) { return h ? h->S.N : 0; }
+
+int evg_state_bytes_per_env(const evg_handle* h) {
+    (void)h;
+    return 24 * 4 + 6 * 4 + NN * 2 + 4 + 4 + 2 * NU * 8 + 2 * 4;   // grp, stamp, node, env, episode, health, ep_ret
+}
+
+int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int rc = launch_reset(h->S, mask, obs_out, h->cfg.obs_dtype, stream);
+    if (rc) return fail(EVG_ERR_HIP, "reset launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward_out, uint8_t* done_out, int8_t* winner_out,
+             int32_t* scores_out, uint8_t* status_out, void* stream) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0};
+    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
+    if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_observe(evg_handle* h, void* obs_out, void* stream) {
+    if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
+    if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
+    if (!h || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int rc = launch_random_actions(h->S, actions_out, stream);
+    if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health, int32_t* env) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t)h->S.N;
+    if (groups) {
+        std::vector<uint32_t> g(24 * N), st(6 * N);
+        HIP_TRY(hipMemcpy(g.data(), h->S.grp, g.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(st.data(), h->S.stamp, st.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < N; ++e)
+            for (int r = 0; r < 24; ++r) {
+                const uint32_t w = g[(size_t)r * N + e];
+                int32_t* o = groups + (e * 24 + r) * 8;
+                const uint32_t mode = (w & G_MODE_M) >> G_MODE_S, dest = (w & G_DEST_M) >> G_DEST_S;
+                const int cnt = __builtin_popcount(w & G_MASK_M);
+                o[0] = (int32_t)(w & G_LOC_M); o[1] = dest ? (int32_t)dest : -1; o[2] = (int32_t)((w & G_DIST_M) >> G_DIST_S);
+                o[3] = mode == MODE_READY; o[4] = mode == MODE_MOVING; o[5] = cnt == 0; o[6] = cnt;
+                o[7] = (int32_t)((st[(size_t)(r >> 2) * N + e] >> (8 * (r & 3))) & 0xFFu);
+            }
+    }
+    if (nodes) {
+        std::vector<uint16_t> nd(NN * N);
+        HIP_TRY(hipMemcpy(nd.data(), h->S.node, nd.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < N; ++e)
+            for (int n = 0; n < NN; ++n) {
+                const uint16_t w = nd[(size_t)n * N + e];
+                nodes[(e * NN + n) * 2] = (int32_t)(w & 0x3FF) - 512;
+                nodes[(e * NN + n) * 2 + 1] = (int32_t)((w >> 10) & 3) - 1;
+            }
+    }
+    if (health) HIP_TRY(hipMemcpy(health, h->S.health, 2 * NU * N * sizeof(double), hipMemcpyDeviceToHost));
+    if (env) {
+        std::vector<uint32_t> ev(N), ep(N);
+        HIP_TRY(hipMemcpy(ev.data(), h->S.env, N * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ep.data(), h->S.episode, N * 4, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < N; ++e) {
+            env[e * 4] = (int32_t)(ev[e] & 0xFF); env[e * 4 + 1] = (int32_t)((ev[e] >> 8) & 3);
+            env[e * 4 + 2] = (int32_t)ep[e]; env[e * 4 + 3] = 0;
+        }
+    }
+    return EVG_OK;
+}
+
+int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, const double* health, const int32_t* env) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (!groups || !nodes || !health || !env) return fail(EVG_ERR_INVALID, "set_state needs all four arrays");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t)h->S.N;
+    std::vector<uint32_t> g(24 * N), st(6 * N, 0u), ev(N), ep(N);
+    std::vector<uint16_t> nd(NN * N);
+    for (size_t e = 0; e < N; ++e) {
+        for (int r = 0; r < 24; ++r) {
+            const int32_t* o = groups + (e * 24 + r) * 8;
+            const int p = r / 12, k = r % 12, size = kGroupSize[k];
+            const double* hp = health + e * 2 * NU + p * NU + 8 * k;
+            uint32_t mask = 0;
+            for (int s = 0; s < size; ++s) mask |= (hp[s] > 0.0 ? 1u : 0u) << s;
+            const int cnt = __builtin_popcount(mask);
+            if (o[0] < 1 || o[0] > NN || o[1] < -1 || o[1] > NN || o[1] == 0 || o[2] < 0 || o[2] > 7 || (o[3] && o[4]) || o[7] < 0 || o[7] > 255)
+                return fail(EVG_ERR_INVALID, "set_state: env %zu group %d has out-of-domain fields", e, r);
+            if (o[6] != cnt || (o[5] != 0) != (cnt == 0))
+                return fail(EVG_ERR_INVALID, "set_state: env %zu group %d count/destroyed disagree with health (count %d, alive %d)", e, r, o[6], cnt);
+            const uint32_t avg = cnt ? (uint32_t)(int)(host_np_sum(hp, size) / (double)cnt) : 0u;
+            const uint32_t mode = o[4] ? MODE_MOVING : (o[3] ? MODE_READY : MODE_IDLE);
+            g[(size_t)r * N + e] = (uint32_t)o[0] | ((uint32_t)(o[1] < 0 ? 0 : o[1]) << G_DEST_S) | ((uint32_t)o[2] << G_DIST_S) |
+                                   (mode << G_MODE_S) | (mask << G_MASK_S) | (avg << G_AVG_S);
+            st[(size_t)(r >> 2) * N + e] |= (uint32_t)o[7] << (8 * (r & 3));
+        }
+        for (int n = 0; n < NN; ++n) {
+            const int cs = nodes[(e * NN + n) * 2], cb = nodes[(e * NN + n) * 2 + 1];
+            if (cs < -511 || cs > 511 || cb < -1 || cb > 1) return fail(EVG_ERR_INVALID, "set_state: env %zu node %d out of domain", e, n + 1);
+            nd[(size_t)n * N + e] = (uint16_t)((cs + 512) | ((cb + 1) << 10));
+        }
+        if (env[e * 4] < 0 || env[e * 4] > 255 || env[e * 4 + 1] < 0 || env[e * 4 + 1] > 3) return fail(EVG_ERR_INVALID, "set_state: env %zu turn/status", e);
+        ev[e] = (uint32_t)env[e * 4] | ((uint32_t)env[e * 4 + 1] << 8);
+        ep[e] = (uint32_t)env[e * 4 + 2];
+    }
+    HIP_TRY(hipMemcpy(h->S.grp, g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->S.stamp, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->S.node, nd.data(), nd.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->S.env, ev.data(), N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->S.episode, ep.data(), N * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->S.health, health, 2 * NU * N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->S.ep_ret, 0, 2 * N * sizeof(float)));
+    HIP_TRY(hipDeviceSynchronize());
+    return EVG_OK;
+}
+
+int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* winner, int64_t* totals) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t)h->S.N;
+    if (returns) HIP_TRY(hipMemcpy(returns, h->S.fin_ret, 2 * N * sizeof(float), hipMemcpyDeviceToHost));
+    if (length) HIP_TRY(hipMemcpy(length, h->S.fin_len, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (winner) HIP_TRY(hipMemcpy(winner, h->S.fin_win, N, hipMemcpyDeviceToHost));
+    if (totals) HIP_TRY(hipMemcpy(totals, h->S.totals, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return EVG_OK;
+}
+
+int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (returns) *returns = h->S.fin_ret;
+    if (length) *length = h->S.fin_len;
+    if (winner) *winner = h->S.fin_win;
+    return EVG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// evg_device.h -- data layout shared by the HIP kernels (evg_kernels.hip) and the C-ABI host
+// side (evg_abi.hip).  gfx950 only.
+//
+// Persistent state, struct-of-arrays over N envs (see DESIGN.md "Data layout in HBM"):
+//   grp    u32 [24][N]   one packed word per group (player p, group k -> row p*12+k), env fastest:
+//                         bits  0-3  location (node ID 1..11)
+//                         bits  4-7  travel_destination (0 = none, the reference's -1)
+//                         bits  8-10 distance_remaining
+//                         bits 11-12 mode: 0 idle, 1 ready (ordered this turn), 2 moving
+//                         bits 13-24 alive mask of the group's (up to 12) unit slots
+//                         bits 25-31 cached int(avg health) of player_state (server.py:491)
+//                         destroyed <=> alive mask == 0 (server.py:623-625)
+//   stamp  u32 [6][N]    arrival turn of each group, 4 x u8 per word (group row r -> word r>>2);
+//                         node-list order of the reference == (stamp, gid) order
+//   node   u16 [11][N]   bits 0-9 controlState+512, bits 10-11 controlledBy+1
+//   env    u32 [N]       bits 0-7 current_turn, bits 8-9 status
+//   episode u32 [N]
+//   health f64 [N][200]  env-major: unitHealth of player p group k at [p*100 + 8k ...]; a group's
+//                         row is one 64-byte (96 for group 11) aligned segment, touched only by combat
+//   ep_ret f32 [2][N], fin_ret f32 [N][2], fin_len i32 [N], fin_win i8 [N], totals u64[4]
+#pragma once
+#include <stdint.h>
+#include "../../include/evg.h"
+
+namespace evg {
+
+constexpr int NP = 2, NG = 12, NN = 11, NU = 100, NA = 7, OBS = 105;
+constexpr int WG = 64;                    // one wavefront per workgroup, one env per lane
+constexpr int REC_WORDS = 65;             // observation record: 130 int16 fields per env
+constexpr int REC_FIELDS = 130;
+constexpr int DESC_MAX = 840;             // descriptors for a unit of up to 4 envs (i16 obs)
+
+// group word fields
+constexpr uint32_t G_LOC_M = 0xFu, G_DEST_S = 4, G_DIST_S = 8, G_MODE_S = 11, G_MASK_S = 13, G_AVG_S = 25;
+constexpr uint32_t G_DEST_M = 0xFu << G_DEST_S, G_DIST_M = 0x7u << G_DIST_S, G_MODE_M = 0x3u << G_MODE_S;
+constexpr uint32_t G_MASK_M = 0xFFFu << G_MASK_S, G_AVG_M = 0x7Fu << G_AVG_S;
+constexpr uint32_t MODE_IDLE = 0, MODE_READY = 1, MODE_MOVING = 2;
+
+struct DevTables {
+    uint64_t adj_row[12];        // nibble j of row i = distance i -> j (0 = not connected)
+    double   defense[12];
+    int32_t  control_points[12];
+    int32_t  team_start[12];
+    int32_t  resource[12];
+    uint64_t p1map_nib;          // nibble i = p1_node_map[i]
+    uint64_t type_nib[2];        // nibble k = unit type of group k
+    uint32_t damage_nib;         // nibble t = damage of unit type t
+    uint32_t armor_byte;         // byte t   = health ("armor") of unit type t
+    int32_t  unit_speed[4], unit_control[4], unit_cost[4];
+    int32_t  group_type[2][12];
+    int32_t  max_turns;
+    uint32_t init_grp[24];       // state right after game_init (server.py:133-209)
+    uint32_t init_node[12];
+    uint32_t reset_rec[REC_WORDS];   // observation record of that state
+    int16_t  reset_obs[2 * OBS];     // and the observation itself
+    int32_t  desc_unit_envs;     // U: envs per descriptor unit (f64 1, f32 2, i16 4)
+    uint16_t obs_desc[DESC_MAX]; // per output element: bit15 const | value, else field | env_in_unit << 8
+};
+
+struct DevState {
+    int32_t   N;
+    int32_t   auto_reset;
+    uint32_t* grp;
+    uint32_t* stamp;
+    uint16_t* node;
+    uint32_t* env;
+    uint32_t* episode;
+    double*   health;
+    float*    ep_ret;
+    float*    fin_ret;
+    int32_t*  fin_len;
+    int8_t*   fin_win;
+    unsigned long long* totals;
+    uint32_t  seed_lo, seed_hi, env_id_base;
+    const DevTables* T;
+};
+
+struct StepIO {
+    const int32_t* actions;
+    void*     obs;
+    float*    reward;
+    uint8_t*  done;
+    int8_t*   winner;
+    int32_t*  scores;
+    uint8_t*  status;
+    int32_t   observe_only;      // 1: only (re)build observations from the current state
+};
+
+// launchers (evg_kernels.hip)
+int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream);
+int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream);
+int launch_random_actions(const DevState& S, int32_t* actions, void* stream);
+
+}  // namespace evg

@@ -1,0 +1,35 @@
+// evg_rng.h -- counter-based RNG of the build (device side): Philox4x32-10, keyed exactly as
+// oracle/rng_spec.py states it (seed, env id, episode, turn, node, player, group, block).
+// Replaces the reference's unseeded global numpy stream (server.py:205,338,562).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace evg {
+
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
+constexpr uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
+constexpr int RNG_COMBAT = 0, RNG_ACTION = 1, RNG_SWARM = 2;
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(PHILOX_M0, c.x), lo0 = PHILOX_M0 * c.x;
+        const uint32_t hi1 = __umulhi(PHILOX_M1, c.z), lo1 = PHILOX_M1 * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    return c;
+}
+
+__device__ __forceinline__ uint4 rng_block(uint32_t seed_lo, uint32_t seed_hi, uint32_t env_id, uint32_t episode,
+                                           int domain, uint32_t block, int turn, int node, int player, int group) {
+    const uint4 ctr = make_uint4((block & 0x0FFFFFFFu) | ((uint32_t)domain << 28),
+                                 ((uint32_t)turn & 0xFFu) | (((uint32_t)node & 0xFu) << 8) | (((uint32_t)player & 1u) << 12) |
+                                     (((uint32_t)group & 0xFu) << 16),
+                                 episode, env_id);
+    return philox4x32_10(ctr, seed_lo, seed_hi);
+}
+
+}  // namespace evg

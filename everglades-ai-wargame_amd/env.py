@@ -1,0 +1,128 @@
+"""EvergladesEnv -- single-game drop-in for gym_everglades.envs.EvergladesEnv
+(gym-everglades/gym_everglades/envs/everglades_env.py:13-173): same constructor attributes,
+`reset(**kwargs) -> {player: float64[105]}`, `step({player: array(7, 2)}) -> (obs, reward, done, {})`,
+so the reference's harness loops (evaluate.py:127-181, demo/random_demo.py:90-113) run unchanged.
+The game runs on the GPU through EvergladesVecEnv(num_envs=1); use the vectorised class for throughput.
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+from .tables import default_tables, tables_from_json
+from .vec_env import EvergladesVecEnv
+
+MAX_SCORE = _lib.MAX_SCORE
+
+
+class _Space(object):
+    """Stand-in used when `gym` is not installed: carries the same shape/bounds information."""
+
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.__dict__.update(kw)
+
+
+def _make_spaces(env):
+    group_low = np.array([1, 0, 0, 0, 0])
+    group_high = np.array([env.num_nodes, len(env.unit_classes), 100, 1, env.num_units])
+    cp_low = np.array([0, 0, -100, -1])
+    cp_high = np.array([1, 1, 100, env.num_units])
+    low = np.concatenate([[1], np.tile(cp_low, env.num_nodes), np.tile(group_low, env.num_groups)])
+    high = np.concatenate([[env.num_turns + 1], np.tile(cp_high, env.num_nodes), np.tile(group_high, env.num_groups)])
+    try:
+        from gym.spaces import Tuple, Discrete, Box
+        act = Tuple((Discrete(env.num_groups), Discrete(env.num_nodes + 1)) * env.num_actions_per_turn)
+        obs = Box(low=low, high=high)
+    except Exception:
+        act = _Space("Tuple", spaces=tuple(_Space("Discrete", n=n) for n in (env.num_groups, env.num_nodes + 1) * env.num_actions_per_turn))
+        obs = _Space("Box", low=low, high=high, shape=low.shape)
+    return act, obs
+
+
+def canonical_actions(action):
+    """What the server does with a player's array before using it: it must have 2 columns, only the
+    first 7 rows count, values are truncated to int (server.py:225-232).  Missing rows become the
+    always-invalid order (0, 0)."""
+    a = np.asarray(action)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise AssertionError("Did not receive 2 columns for a player's action")
+    a = a[:7].astype(int)
+    out = np.zeros((7, 2), np.int32)
+    out[:len(a)] = np.clip(a, -1, 12)       # anything outside [0, 11] is an invalid order
+    return out
+
+
+class EvergladesEnv(object):
+    metadata = {"render.modes": []}
+
+    def __init__(self, seed=None, device=None, env_id=0):
+        self.num_turns = 150
+        self.num_units = 100
+        self.num_groups = 12
+        self.num_nodes = 11
+        self.num_actions_per_turn = 7
+        self.unit_classes = ["controller", "striker", "tank"]
+        self.action_space, self.observation_space = _make_spaces(self)
+        self.viewer = None
+        self._seed = int.from_bytes(os.urandom(8), "little") if seed is None else int(seed)   # the reference is unseeded
+        self._device = device
+        self._env_id = int(env_id)
+        self._vec = None
+        self._cfg_key = None
+        self.players = None
+
+    def _ensure(self, config_dir, map_file, unit_file):
+        key = (config_dir, map_file, unit_file)
+        if self._vec is None or key != self._cfg_key:
+            if self._vec is not None:
+                self._vec.close()
+            tables = default_tables() if (map_file is None and unit_file is None) else tables_from_json(map_file, unit_file, config_dir)
+            self._vec = EvergladesVecEnv(1, device=self._device, seed=self._seed, env_id_base=self._env_id, obs_dtype="float64", auto_reset=False, tables=tables)
+            self._cfg_key = key
+
+    def _obs_dict(self, obs):
+        o = obs[0].cpu().numpy()
+        return {p: o[i].copy() for i, p in enumerate(self.sorted_pks)}
+
+    def reset(self, **kwargs):
+        self.players = kwargs.get("players")
+        config_dir, map_file, unit_file = kwargs.get("config_dir"), kwargs.get("map_file"), kwargs.get("unit_file")
+        kwargs.get("output_dir")        # accepted and ignored, like the reference (everglades_env.py:82,100)
+        kwargs.get("pnames")
+        self.debug = kwargs.get("debug", False)
+        assert len(self.players) == 2, "Must have exactly two players"
+        self.pks = self.players.keys()
+        self.sorted_pks = sorted(self.pks)
+        assert self.sorted_pks == [0, 1], "Given player number not included in map configuration file starting locations"
+        self._ensure(config_dir, map_file, unit_file)
+        return self._obs_dict(self._vec.reset())
+
+    def step(self, actions):
+        a = np.zeros((1, 2, 7, 2), np.int32)
+        for i, p in enumerate(self.sorted_pks):
+            if p not in actions:
+                print("Player {} not found in input action dictionary".format(p))   # server.py:219-221
+                continue
+            a[0, i] = canonical_actions(actions[p])
+        obs, _, done, info = self._vec.step(a)
+        observations = self._obs_dict(obs)
+        scores = info["scores"][0].cpu().numpy()
+        status = int(info["status"][0].item())
+        reward = {p: 0 for p in self.players}
+        d = 0
+        if status != 0:                                  # everglades_env.py:39-45
+            d = 1
+            if scores[0] != scores[1]:
+                reward[0] = 1 if scores[0] > scores[1] else 0
+                reward[1] = 1 if scores[1] > scores[0] else -1
+        else:                                            # everglades_env.py:55-57
+            reward[0] = float(scores[0]) / MAX_SCORE
+            reward[1] = float(scores[1]) / MAX_SCORE
+        return observations, reward, d, {}
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering (everglades_renderer.py) is outside the accelerated path")
+
+    def close(self):
+        pass

@@ -1,0 +1,181 @@
+"""EvergladesVecEnv -- N concurrent two-player Everglades games on one MI355X.
+
+Host-side mirror of the reference's Gym interface (gym_everglades/envs/everglades_env.py) over the
+C-ABI of include/evg.h: `reset()` and `step()` have the reference's meaning, vectorised over a leading
+env axis, with all I/O in caller-visible torch tensors on the GPU.  PyTorch is used only for device
+memory and streams; the game itself runs in the HIP kernels of csrc/evg_kernels.hip.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .tables import default_tables, tables_from_json
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class EvergladesVecEnv(object):
+    # constants of the reference environment (everglades_env.py:17-22)
+    num_turns = 150
+    num_units = _lib.NUM_UNITS
+    num_groups = _lib.NUM_GROUPS
+    num_nodes = _lib.NUM_NODES
+    num_actions_per_turn = _lib.NUM_ACTIONS
+    unit_classes = ["controller", "striker", "tank"]
+    obs_len = _lib.OBS_LEN
+
+    def __init__(self, num_envs, device=None, seed=0, env_id_base=0, obs_dtype="float32", auto_reset=True, tables=None,
+                 map_file=None, unit_file=None, config_dir=None):
+        torch = _torch()
+        self.L = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.EvgError("EvergladesVecEnv needs a HIP device (MI355X); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EvgError("device must be a cuda (HIP) device, got %s" % (self.device,))
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        self.num_envs = int(num_envs)
+        self.seed, self.env_id_base, self.auto_reset = int(seed), int(env_id_base), bool(auto_reset)
+        names = {"float32": (_lib.OBS_F32, torch.float32), "float64": (_lib.OBS_F64, torch.float64), "int16": (_lib.OBS_I16, torch.int16)}
+        key = str(obs_dtype).replace("torch.", "")
+        if key not in names:
+            raise ValueError("obs_dtype must be float32, float64 or int16")
+        self._obs_code, self.obs_dtype = names[key]
+        if tables is None:
+            tables = default_tables() if (map_file is None and unit_file is None) else tables_from_json(map_file, unit_file, config_dir)
+        self.tables = tables
+        cfg = _lib.EvgConfig()
+        cfg.struct_size, cfg.abi_version = C.sizeof(_lib.EvgConfig), _lib.ABI_VERSION
+        cfg.num_envs, cfg.device_id = self.num_envs, dev_index
+        cfg.seed, cfg.env_id_base = self.seed & 0xFFFFFFFFFFFFFFFF, self.env_id_base
+        cfg.obs_dtype, cfg.auto_reset = self._obs_code, int(self.auto_reset)
+        cfg.tables = tables
+        h = C.c_void_p()
+        _lib.check(self.L.evg_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        N = self.num_envs
+        with torch.cuda.device(self.device):
+            self.obs = torch.zeros((N, 2, _lib.OBS_LEN), dtype=self.obs_dtype, device=self.device)
+            self.reward = torch.zeros((N, 2), dtype=torch.float32, device=self.device)
+            self.done = torch.zeros((N,), dtype=torch.uint8, device=self.device)
+            self.winner = torch.full((N,), -1, dtype=torch.int8, device=self.device)
+            self.scores = torch.zeros((N, 2), dtype=torch.int32, device=self.device)
+            self.status = torch.zeros((N,), dtype=torch.uint8, device=self.device)
+            self._actions = torch.zeros((N, 2, _lib.NUM_ACTIONS, 2), dtype=torch.int32, device=self.device)
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _ptr(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _torch().cuda.synchronize(self.device)
+            self.L.evg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ Gym-style API
+    def reset(self, mask=None):
+        """Start a new episode in every env (or in envs where mask != 0).  Returns obs [N, 2, 105]
+        (everglades_env.py:75-116)."""
+        torch = _torch()
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            assert m.shape == (self.num_envs,)
+        _lib.check(self.L.evg_reset(self._h, self._ptr(m), self._ptr(self.obs), self._stream()))
+        return self.obs
+
+    def _as_actions(self, actions):
+        torch = _torch()
+        if isinstance(actions, dict):       # reference-style {player: array(7, 2)} per env is handled by EvergladesEnv
+            raise TypeError("pass a [N, 2, 7, 2] tensor; dict actions are the single-env API (EvergladesEnv)")
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dtype != torch.int32:
+            a = a.to(torch.int32)           # truncation, like action.astype(int) (server.py:232)
+        a = a.contiguous()
+        if a.shape != (self.num_envs, 2, _lib.NUM_ACTIONS, 2):
+            raise ValueError("actions must have shape [N, 2, 7, 2], got %s" % (tuple(a.shape),))
+        return a
+
+    def step(self, actions):
+        """One turn of every game.  Returns (obs [N,2,105], reward [N,2] f32, done [N] u8, info) where info has
+        winner [N] i8, scores [N,2] i32, status [N] u8 (everglades_env.py:32-73).  The tensors are the env's own
+        output buffers and are overwritten by the next call."""
+        a = self._as_actions(actions)
+        _lib.check(self.L.evg_step(self._h, self._ptr(a), self._ptr(self.obs), self._ptr(self.reward), self._ptr(self.done),
+                                   self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status), self._stream()))
+        return self.obs, self.reward, self.done, dict(winner=self.winner, scores=self.scores, status=self.status)
+
+    def observe(self):
+        _lib.check(self.L.evg_observe(self._h, self._ptr(self.obs), self._stream()))
+        return self.obs
+
+    def random_actions(self, out=None):
+        """On-device equivalent of agents/State_Machine/random_actions.py for both players of every env."""
+        out = self._actions if out is None else out
+        _lib.check(self.L.evg_random_actions(self._h, self._ptr(out), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ state exchange / stats
+    def get_state(self):
+        N = self.num_envs
+        s = dict(groups=np.zeros((N, 2, 12, 8), np.int32), nodes=np.zeros((N, 11, 2), np.int32),
+                 health=np.zeros((N, 2, 100), np.float64), env=np.zeros((N, 4), np.int32))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.L.evg_get_state(self._h, p(s["groups"]), p(s["nodes"]), p(s["health"]), p(s["env"])))
+        return s
+
+    def set_state(self, groups, nodes, health, env):
+        N = self.num_envs
+        g = np.ascontiguousarray(groups, np.int32)
+        n = np.ascontiguousarray(nodes, np.int32)
+        h = np.ascontiguousarray(health, np.float64)
+        e = np.ascontiguousarray(env, np.int32)
+        if g.shape != (N, 2, 12, 8) or n.shape != (N, 11, 2) or h.shape != (N, 2, 100) or e.shape != (N, 4):
+            raise ValueError("set_state: wrong array shapes")
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.L.evg_set_state(self._h, p(g), p(n), p(h), p(e)))
+
+    def episode_stats(self):
+        N = self.num_envs
+        r, ln, w, tot = np.zeros((N, 2), np.float32), np.zeros(N, np.int32), np.zeros(N, np.int8), np.zeros(4, np.int64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.L.evg_episode_stats(self._h, p(r), p(ln), p(w), p(tot)))
+        return dict(returns=r, length=ln, winner=w, totals=tot)
+
+    def episode_stats_device(self):
+        """Zero-copy torch views of the per-env results of the last finished episode (for the multi-GPU gather)."""
+        torch = _torch()
+        pr, pl, pw = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(self.L.evg_episode_stats_device(self._h, C.byref(pr), C.byref(pl), C.byref(pw)))
+        N = self.num_envs
+
+        def view(ptr, shape, dtype, itemsize):
+            n = int(np.prod(shape))
+            iface = dict(shape=(n,), typestr={4: "<f4" if dtype == torch.float32 else "<i4", 1: "|i1"}[itemsize],
+                         data=(ptr.value, False), version=2)
+            holder = type("_Dev", (), {"__cuda_array_interface__": iface})()
+            return torch.as_tensor(holder, device=self.device).view(*shape)
+
+        return dict(returns=view(pr, (N, 2), torch.float32, 4), length=view(pl, (N,), torch.int32, 4),
+                    winner=view(pw, (N,), torch.int8, 1))
+
+    @property
+    def state_bytes_per_env(self):
+        return int(self.L.evg_state_bytes_per_env(self._h))

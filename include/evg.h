@@ -105,8 +105,8 @@ typedef struct evg_handle evg_handle;
 void evg_default_tables(evg_tables* t);
 
 /* Replaces EvergladesGame.__init__/board_init/unitTypes_init (server.py:14-131): tables are parsed
- * once by the host and copied to the device; state for N envs is allocated (uninitialised until
- * the first evg_reset). */
+ * once by the host and copied to the device; state for N envs is allocated and every env is put in
+ * the game_init position (episode counter -1, so the first evg_reset starts episode 0). */
 int evg_create(const evg_config* cfg, evg_handle** out);
 void evg_destroy(evg_handle* h);
 
@@ -132,6 +132,10 @@ int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream);
  * terminal outputs. */
 int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward_out, uint8_t* done_out,
              int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream);
+
+/* Observations of the current state without stepping (after evg_set_state, or to re-read them):
+ * the board_state/player_state half of step (server.py:382-501). obs_out as in evg_step. */
+int evg_observe(evg_handle* h, void* obs_out, void* stream);
 
 /* Input generator for the benchmark configs: the on-device equivalent of
  * agents/State_Machine/random_actions.py:38-46 for every env and both players, keyed by

@@ -81,11 +81,9 @@ class _RandomProxy(object):
             return 0  # the two focus draws (game_init / game_end) are unobservable
         L = fr.f_locals
         o = self._o
-        pid, i, j, counts = L["pid"], L["i"], L["j"], L["counts"]
-        ordinal = int(sum(int(c) for c in counts[pid][:i])) + int(j)
         o.draws += 1
         return rng_spec.combat_draw(o.seed, o.env_id, o.episode, L["self"].current_turn, L["node"].ID,
-                                    pid, ordinal, int(n))
+                                    L["pid"], int(L["gid"]), int(L["j"]), int(n))
 
     def __getattr__(self, k):
         return getattr(np.random, k)

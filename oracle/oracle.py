@@ -84,7 +84,7 @@ def lib():
         L.evo_observe.argtypes = [C.c_void_p, C.c_void_p]
         L.evo_episode_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.evo_combat_draw.restype = C.c_int
-        L.evo_combat_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.evo_combat_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.evo_np_sum.restype = C.c_double
         L.evo_np_sum.argtypes = [C.c_void_p, C.c_int]
         L.evo_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -178,8 +178,8 @@ def np_sum(a):
     return lib().evo_np_sum(_p(a), a.size)
 
 
-def combat_draw(seed, env_id, episode, turn, node, player, ordinal, n):
-    return lib().evo_combat_draw(seed, env_id, episode, turn, node, player, ordinal, n)
+def combat_draw(seed, env_id, episode, turn, node, player, group, j, n):
+    return lib().evo_combat_draw(seed, env_id, episode, turn, node, player, group, j, n)
 
 
 def philox(ctr, key):

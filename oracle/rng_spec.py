@@ -12,11 +12,14 @@ plants into the imported reference all implement exactly this.
 Generator: Philox4x32-10 (Salmon et al., SC'11), 64-bit key, 128-bit counter.
 
   key     = (seed & 0xffffffff, seed >> 32)
-  counter = (block | domain << 28,  turn | node << 8 | player << 12,  episode,  env_id & 0xffffffff)
+  counter = (block | domain << 28,  turn | node << 8 | player << 12 | group << 16,  episode,
+             env_id & 0xffffffff)
 
-  combat  (domain 0): the a-th attacking unit (a = units of earlier groups in node-list order + j)
-                      of `player` at `node` on `turn` uses word (a & 3) of block (a >> 2);
+  combat  (domain 0): the j-th alive unit (j = the loop index of server.py:561) of attacking group
+                      `group` of `player` at `node` on `turn` uses word (j & 3) of block (j >> 2);
                       target index uid = (word * n) >> 32 with n = opposing alive units at the node.
+                      (Keyed by group and unit, not by a node-wide ordinal, so that a GPU lane can
+                      draw for its group without knowing the groups listed before it.)
   actions (domain 1): the on-device stand-in for agents/State_Machine/random_actions.py:38-46
                       (7 distinct groups of 12, 7 distinct nodes of 1..11): blocks 0..3 give 16
                       words; partial Fisher-Yates, see `random_action_rows`.
@@ -48,17 +51,17 @@ def _key(seed):
     return seed & MASK, seed >> 32
 
 
-def _ctr(domain, block, turn, node, player, episode, env_id):
+def _ctr(domain, block, turn, node, player, episode, env_id, group=0):
     return ((block & 0x0FFFFFFF) | (domain << 28),
-            (turn & 0xFF) | ((node & 0xF) << 8) | ((player & 1) << 12),
+            (turn & 0xFF) | ((node & 0xF) << 8) | ((player & 1) << 12) | ((group & 0xF) << 16),
             episode & MASK,
             env_id & MASK)
 
 
-def combat_draw(seed, env_id, episode, turn, node, player, ordinal, n):
-    """Target index in [0, n) for attacker `ordinal` (see module docstring)."""
-    w = philox4x32_10(_ctr(DOMAIN_COMBAT, ordinal >> 2, turn, node, player, episode, env_id), _key(seed))
-    return (w[ordinal & 3] * int(n)) >> 32
+def combat_draw(seed, env_id, episode, turn, node, player, group, j, n):
+    """Target index in [0, n) for the j-th alive unit of attacking `group` (see module docstring)."""
+    w = philox4x32_10(_ctr(DOMAIN_COMBAT, j >> 2, turn, node, player, episode, env_id, group), _key(seed))
+    return (w[j & 3] * int(n)) >> 32
 
 
 def random_action_rows(seed, env_id, episode, turn, player):

@@ -1,0 +1,215 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C-ABI
+(libevg.so via everglades_amd), against (a) the committed golden fixtures generated from the
+reference and (b) the CPU oracle on the same seeded inputs.  Bit-exact for every integer
+(observations, scores, status, packed state) and for float64 health; float32 rewards within 1e-6
+of the oracle's float64 (tolerance of BASELINE.json north_star: 1e-5)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_initial_state, TRAJ_FILES
+
+pytestmark = pytest.mark.gpu
+REWARD_ATOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def evg():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import everglades_amd
+    return everglades_amd
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def check_state(env, ora_state, what=""):
+    s = env.get_state()
+    for k in ("groups", "nodes", "health", "env"):
+        assert np.array_equal(s[k], ora_state[k]), (what, k)
+
+
+@pytest.mark.parametrize("fname", TRAJ_FILES + ["edit_annihilation.npz"])
+def test_golden_through_abi(evg, fname):
+    d = load_golden(fname)
+    for g in range(len(d["length"])):
+        T = int(d["length"][g])
+        env = evg.EvergladesVecEnv(1, seed=int(d["seed"][g]), env_id_base=int(d["env_id"][g]), obs_dtype="float64", auto_reset=False)
+        env.reset()
+        env.set_state(*golden_initial_state(d, g))
+        assert np.array_equal(_np(env.observe())[0], d["obs"][g, 0].astype(np.float64)), ("initial obs", g)
+        for t in range(T):
+            obs, rew, done, info = env.step(d["actions"][g, t][None].astype(np.int32))
+            assert np.array_equal(_np(obs)[0], d["obs"][g, t + 1].astype(np.float64)), ("obs", fname, g, t)
+            assert np.array_equal(_np(info["scores"])[0], d["scores"][g, t]), ("scores", g, t)
+            assert int(info["status"][0]) == d["status"][g, t] and int(done[0]) == d["done"][g, t]
+            assert np.allclose(_np(rew)[0], d["reward"][g, t], rtol=0, atol=REWARD_ATOL)
+            s = env.get_state()
+            assert np.array_equal(s["health"][0], d["health"][g, t + 1]), ("health bits", fname, g, t)
+            assert np.array_equal(s["groups"][0], d["groups"][g, t + 1]), ("groups", fname, g, t)
+            assert np.array_equal(s["nodes"][0], d["nodes"][g, t + 1]), ("nodes", fname, g, t)
+        env.close()
+
+
+def test_bulk_random_matches_reference(evg):
+    """The 120 reference games of bulk_random.npz: on-device action generation + step reproduce the
+    reference's per-turn observation checksums, final scores/status and final float64 health."""
+    d = load_golden("bulk_random.npz")
+    B = len(d["length"])
+    env = evg.EvergladesVecEnv(B, seed=int(d["seed"]), auto_reset=False)
+    obs = env.reset()
+    assert np.array_equal(_np(obs).sum(axis=2).astype(np.int32), d["obs_sum"][:, 0])
+    for t in range(150):
+        obs, rew, done, info = env.step(env.random_actions())
+        live = d["length"] > t
+        assert np.array_equal(_np(obs).astype(np.int64).sum(axis=2).astype(np.int32)[live], d["obs_sum"][live, t + 1]), t
+    assert np.array_equal(_np(info["scores"]), d["scores"]) and np.array_equal(_np(info["status"]), d["status"])
+    assert np.array_equal(env.get_state()["health"], d["health_final"])
+    st = env.episode_stats()
+    w0 = int((d["scores"][:, 0] > d["scores"][:, 1]).sum())
+    w1 = int((d["scores"][:, 1] > d["scores"][:, 0]).sum())
+    assert st["totals"].tolist() == [B, w0, w1, B - w0 - w1]
+    env.close()
+
+
+@pytest.mark.parametrize("N", [1, 65, 1000])
+def test_random_rollout_vs_oracle(evg, oracle_mod, N):
+    """Full 150-turn random-vs-random episodes; N chosen to exercise partial workgroups."""
+    seed = 4242 + N
+    env = evg.EvergladesVecEnv(N, seed=seed, env_id_base=17, auto_reset=False)
+    ora = oracle_mod.Oracle(N, seed=seed, env_id_base=17)
+    assert np.array_equal(_np(env.reset()).astype(np.float64), ora.reset())
+    for t in range(152):     # two extra steps: finished envs stay frozen and repeat their outputs
+        a = env.random_actions()
+        assert np.array_equal(_np(a), ora.random_actions()), ("action generator", t)
+        obs, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(_np(a))
+        assert np.array_equal(_np(obs).astype(np.float64), o_obs), ("obs", t)
+        assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(info["status"]), o_info["status"])
+        assert np.array_equal(_np(info["winner"]), o_info["winner"]) and np.array_equal(_np(done), o_done)
+        assert np.allclose(_np(rew), o_rew, rtol=0, atol=REWARD_ATOL)
+        if t % 25 == 0 or t >= 149:
+            check_state(env, ora.get_state(), t)
+    st, ost = env.episode_stats(), ora.episode_stats()
+    assert np.array_equal(st["totals"], ost["totals"]) and np.array_equal(st["winner"], ost["winner"])
+    assert np.array_equal(st["length"], ost["length"]) and np.allclose(st["returns"], ost["returns"], rtol=1e-6, atol=1e-5)
+    env.close()
+
+
+@pytest.mark.parametrize("policy", ["rush", "brawl", "wild"])
+def test_policies_with_auto_reset_vs_oracle(evg, oracle_mod, policy):
+    """Branch-divergent mixes: base rushes end by BaseCapture after ~30-45 turns (auto-reset desynchronises
+    the envs), brawls fight at node 6 every turn, 'wild' sends out-of-domain and duplicate orders."""
+    from gen_policies import policy_actions
+    N, seed = 192, 99
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    obs = _np(env.reset()).astype(np.float64)
+    assert np.array_equal(obs, ora.reset())
+    rng = np.random.default_rng(5)
+    for t in range(200):
+        a = policy_actions(policy, obs, t, rng)
+        o, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(a)
+        obs = _np(o).astype(np.float64)
+        assert np.array_equal(obs, o_obs), (policy, "obs", t)
+        assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(info["status"]), o_info["status"])
+        assert np.array_equal(_np(done), o_done) and np.allclose(_np(rew), o_rew, rtol=0, atol=REWARD_ATOL)
+        if t % 40 == 39:
+            check_state(env, ora.get_state(), (policy, t))
+    st, ost = env.episode_stats(), ora.episode_stats()
+    assert np.array_equal(st["totals"], ost["totals"]) and st["totals"][0] > 0
+    assert np.array_equal(st["winner"], ost["winner"]) and np.array_equal(st["length"], ost["length"])
+    env.close()
+
+
+def test_obs_dtypes_agree(evg):
+    N, seed = 130, 7
+    envs = [evg.EvergladesVecEnv(N, seed=seed, obs_dtype=dt, auto_reset=True) for dt in ("float32", "float64", "int16")]
+    obs = [_np(e.reset()).astype(np.float64) for e in envs]
+    assert np.array_equal(obs[0], obs[1]) and np.array_equal(obs[0], obs[2])
+    for t in range(60):
+        a = envs[0].random_actions().clone()
+        outs = [_np(e.step(a)[0]).astype(np.float64) for e in envs]
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), t
+    for e in envs:
+        e.close()
+
+
+def test_masked_reset_and_state_roundtrip(evg, oracle_mod):
+    N, seed = 100, 31
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=False)
+    ora = oracle_mod.Oracle(N, seed=seed)
+    env.reset(); ora.reset()
+    for t in range(30):
+        a = env.random_actions()
+        env.step(a); ora.step(_np(a))
+    mask = (np.arange(N) % 3 == 0).astype(np.uint8)
+    before = _np(env.obs).copy()
+    o1 = _np(env.reset(mask)).astype(np.float64)
+    o2 = ora.reset(mask)
+    assert np.array_equal(o1[mask != 0], o2[mask != 0])
+    assert np.array_equal(o1[mask == 0], before[mask == 0].astype(np.float64))       # untouched rows
+    check_state(env, ora.get_state(), "after masked reset")
+    # get_state -> set_state is the identity on the packed state, and observe() reproduces the observations
+    s = env.get_state()
+    env2 = evg.EvergladesVecEnv(N, seed=seed, auto_reset=False)
+    env2.reset()
+    env2.set_state(s["groups"], s["nodes"], s["health"], s["env"])
+    check_state(env2, s, "roundtrip")
+    assert np.array_equal(_np(env2.observe()).astype(np.float64), ora.observe())
+    for t in range(20):
+        a = env.random_actions()
+        o_a, o_b = env.step(a)[0], env2.step(a)[0]
+        assert np.array_equal(_np(o_a), _np(o_b))
+    env.close(); env2.close()
+
+
+def test_single_env_dropin_matches_golden(evg):
+    """EvergladesEnv (dict API of everglades_env.py) replays a reference trajectory, float action arrays included."""
+    d = load_golden("traj_wild.npz")
+    g = 0
+    env = evg.EvergladesEnv(seed=int(d["seed"][g]), env_id=int(d["env_id"][g]))
+    obs = env.reset(players={0: None, 1: None}, config_dir=None, map_file=None, unit_file=None, output_dir="x", pnames={0: "a", 1: "b"}, debug=False)
+    assert env.num_actions_per_turn == 7 and env.observation_space.shape == (105,)
+    assert sorted(obs.keys()) == [0, 1] and obs[0].dtype == np.float64 and obs[0].shape == (105,)
+    env._vec.set_state(*golden_initial_state(d, g))      # this fixture game is episode index d["episode"][g]
+    for t in range(int(d["length"][g])):
+        acts = {0: d["actions"][g, t, 0].astype(np.float64) + 0.25, 1: d["actions"][g, t, 1].astype(np.float64)}
+        obs, reward, done, info = env.step(acts)
+        assert np.array_equal(obs[0], d["obs"][g, t + 1, 0].astype(np.float64)) and np.array_equal(obs[1], d["obs"][g, t + 1, 1].astype(np.float64))
+        assert reward[0] == d["reward"][g, t, 0] and reward[1] == d["reward"][g, t, 1] and done == d["done"][g, t] and info == {}
+
+
+def test_full_size_properties(evg, oracle_mod):
+    """BASELINE config size (65 536 games): size-independent properties after a full auto-reset rollout, and
+    exact agreement of per-env outcomes with the oracle on a sampled sub-range (same global env ids)."""
+    import torch
+    N, seed, steps = 65536, 12345, 160
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    env.reset()
+    for t in range(steps):
+        obs, rew, done, info = env.step(env.random_actions())
+        if t == 149:
+            assert int(done.sum()) == N                       # random vs random: TimeExpired at turn 150 for all
+            sc = info["scores"].clone()
+    s = env.get_state()
+    assert (s["env"][:, 0] == steps - 150).all() and (s["env"][:, 2] == 1).all()
+    alive = (s["health"] > 0).reshape(N, 2, 100)
+    cnt = np.concatenate([alive[:, :, :88].reshape(N, 2, 11, 8).sum(-1), alive[:, :, 88:].sum(-1, keepdims=True)], axis=2)
+    assert np.array_equal(cnt, s["groups"][..., 6]) and (s["health"] >= 0).all() and (s["health"] <= 100).all()
+    o = _np(obs)
+    assert (o[:, :, 0] == steps - 150).all() and (np.abs(o[:, :, 3:45:4]) <= 500).all()
+    assert np.array_equal(o[:, 0, 49::5].astype(np.int64), cnt[:, 0]) and np.array_equal(o[:, 1, 49::5].astype(np.int64), cnt[:, 1])
+    st = env.episode_stats()
+    assert st["totals"][0] == N and st["totals"][1:].sum() == N and (st["length"] == 150).all()
+    # oracle on env ids [30000, 30000+512): same seed and ids -> identical outcomes
+    lo, n = 30000, 512
+    ora = oracle_mod.Oracle(n, seed=seed, env_id_base=lo, auto_reset=True)
+    ora.reset()
+    for t in range(150):
+        _, _, _, oi = ora.step(ora.random_actions())
+    assert np.array_equal(_np(sc)[lo:lo + n], oi["scores"])
+    assert np.array_equal(st["winner"][lo:lo + n], ora.episode_stats()["winner"])
+    env.close()

@@ -110,9 +110,10 @@ def test_rng_contract(oracle_mod):
     for _ in range(300):
         seed = int(r.integers(0, 2 ** 63)) * 2 + 1
         env_id, ep = int(r.integers(0, 2 ** 32)), int(r.integers(0, 2 ** 32))
-        turn, node, pl, ordn, n = int(r.integers(1, 151)), int(r.integers(1, 12)), int(r.integers(0, 2)), int(r.integers(0, 100)), int(r.integers(1, 101))
-        assert oracle_mod.combat_draw(seed, env_id, ep, turn, node, pl, ordn, n) == \
-            rng_spec.combat_draw(seed, env_id, ep, turn, node, pl, ordn, n)
+        turn, node, pl, n = int(r.integers(1, 151)), int(r.integers(1, 12)), int(r.integers(0, 2)), int(r.integers(1, 101))
+        grp, j = int(r.integers(0, 12)), int(r.integers(0, 12))
+        assert oracle_mod.combat_draw(seed, env_id, ep, turn, node, pl, grp, j, n) == \
+            rng_spec.combat_draw(seed, env_id, ep, turn, node, pl, grp, j, n)
     o = oracle_mod.Oracle(4, seed=77, env_id_base=1000)
     o.reset()
     a = o.random_actions()
