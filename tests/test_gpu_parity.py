@@ -183,33 +183,35 @@ def test_single_env_dropin_matches_golden(evg):
 
 
 def test_full_size_properties(evg, oracle_mod):
-    """BASELINE config size (65 536 games): size-independent properties after a full auto-reset rollout, and
-    exact agreement of per-env outcomes with the oracle on a sampled sub-range (same global env ids)."""
-    import torch
+    """BASELINE config size (65 536 games): size-independent properties after an auto-reset rollout, and
+    step-by-step agreement with the oracle on a sampled sub-range (same seed, same global env ids)."""
     N, seed, steps = 65536, 12345, 160
+    lo, n = 30000, 512
     env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
-    env.reset()
+    ora = oracle_mod.Oracle(n, seed=seed, env_id_base=lo, auto_reset=True)
+    env.reset(); ora.reset()
+    finished = np.zeros(N, np.int64)
     for t in range(steps):
         obs, rew, done, info = env.step(env.random_actions())
-        if t == 149:
-            assert int(done.sum()) == N                       # random vs random: TimeExpired at turn 150 for all
-            sc = info["scores"].clone()
+        o_obs, o_rew, o_done, o_info = ora.step(ora.random_actions())
+        assert np.array_equal(_np(info["scores"][lo:lo + n]), o_info["scores"]) and np.array_equal(_np(done[lo:lo + n]), o_done), t
+        assert np.array_equal(_np(obs[lo:lo + n]).astype(np.float64), o_obs), t
+        finished += _np(done).astype(np.int64)
+        if t < 149:
+            assert int(info["status"].eq(1).sum()) == 0            # TimeExpired only at turn 150
+    assert (finished >= 1).all() and finished.sum() < 1.05 * N      # nearly every random game runs the full 150 turns
     s = env.get_state()
-    assert (s["env"][:, 0] == steps - 150).all() and (s["env"][:, 2] == 1).all()
     alive = (s["health"] > 0).reshape(N, 2, 100)
     cnt = np.concatenate([alive[:, :, :88].reshape(N, 2, 11, 8).sum(-1), alive[:, :, 88:].sum(-1, keepdims=True)], axis=2)
     assert np.array_equal(cnt, s["groups"][..., 6]) and (s["health"] >= 0).all() and (s["health"] <= 100).all()
+    assert np.array_equal(s["groups"][..., 5] != 0, cnt == 0) and (s["env"][:, 1] == 0).all()
     o = _np(obs)
-    assert (o[:, :, 0] == steps - 150).all() and (np.abs(o[:, :, 3:45:4]) <= 500).all()
+    assert np.array_equal(o[:, 0, 0].astype(np.int64), s["env"][:, 0]) and (np.abs(o[:, :, 3:45:4]) <= 500).all()
     assert np.array_equal(o[:, 0, 49::5].astype(np.int64), cnt[:, 0]) and np.array_equal(o[:, 1, 49::5].astype(np.int64), cnt[:, 1])
-    st = env.episode_stats()
-    assert st["totals"][0] == N and st["totals"][1:].sum() == N and (st["length"] == 150).all()
-    # oracle on env ids [30000, 30000+512): same seed and ids -> identical outcomes
-    lo, n = 30000, 512
-    ora = oracle_mod.Oracle(n, seed=seed, env_id_base=lo, auto_reset=True)
-    ora.reset()
-    for t in range(150):
-        _, _, _, oi = ora.step(ora.random_actions())
-    assert np.array_equal(_np(sc)[lo:lo + n], oi["scores"])
-    assert np.array_equal(st["winner"][lo:lo + n], ora.episode_stats()["winner"])
+    # opposing-unit columns of board_state sum to the opponent's alive units (every non-destroyed group is listed at one node)
+    assert np.array_equal(o[:, 0, 4:45:4].sum(1).astype(np.int64), cnt[:, 1].sum(1)) and np.array_equal(o[:, 1, 4:45:4].sum(1).astype(np.int64), cnt[:, 0].sum(1))
+    st, ost = env.episode_stats(), ora.episode_stats()
+    assert st["totals"][0] == finished.sum() and st["totals"][1:].sum() == st["totals"][0]
+    assert np.array_equal(st["winner"][lo:lo + n], ost["winner"]) and np.array_equal(st["length"][lo:lo + n], ost["length"])
+    assert np.array_equal(s["health"][lo:lo + n], ora.get_state()["health"])
     env.close()
