@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "evg_device.h"
@@ -46,6 +47,8 @@ struct evg_handle {
     DevState S;
     DevTables* d_tables = nullptr;
     std::vector<void*> allocs;
+    std::vector<hipEvent_t> events;     // evg_rollout_random timing
+    uint32_t ablate = 0;                // EVG_ABLATE (diagnostic)
 };
 
 template <typename Tp>
@@ -229,6 +232,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
 
     evg_handle* h = new evg_handle();
     h->cfg = *cfg;
+    if (const char* ab = getenv("EVG_ABLATE")) h->ablate = (uint32_t)strtoul(ab, nullptr, 0);
     int rc = build_dev_tables(cfg, &h->host_tables);
     if (rc != EVG_OK) { delete h; return rc; }
     const size_t N = (size_t)cfg->num_envs;
@@ -274,6 +278,7 @@ void evg_destroy(evg_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device_id);
     for (void* p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     delete h;
 }
 
@@ -297,7 +302,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0};
+    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, h->ablate};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -306,7 +311,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
 int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -317,6 +322,41 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     const int rc = launch_random_actions(h->S, actions_out, stream);
     if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_rollout_random(evg_handle* h, int steps, int32_t* actions_buf, void* obs_out, float* reward_out, uint8_t* done_out,
+                       int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (steps < 1 || !actions_buf || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, actions_buf, reward_out, done_out required");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (step_kernel_ms) {
+        while (h->events.size() < (size_t)2 * steps) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            h->events.push_back(ev);
+        }
+    }
+    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, h->ablate};
+    for (int i = 0; i < steps; ++i) {
+        int rc = launch_random_actions(h->S, actions_buf, stream);
+        if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * i], s));
+        rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
+        if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
+        if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * i + 1], s));
+    }
+    if (step_kernel_ms) {
+        HIP_TRY(hipStreamSynchronize(s));
+        double tot = 0.0;
+        for (int i = 0; i < steps; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]));
+            tot += ms;
+        }
+        *step_kernel_ms = (float)(tot / steps);
+    }
     return EVG_OK;
 }
 

@@ -84,6 +84,7 @@ struct StepIO {
     int32_t*  scores;
     uint8_t*  status;
     int32_t   observe_only;      // 1: only (re)build observations from the current state
+    uint32_t  ablate;            // diagnostic: bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
 };
 
 // launchers (evg_kernels.hip)

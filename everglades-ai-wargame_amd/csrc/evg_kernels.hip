@@ -20,24 +20,35 @@
 
 namespace evg {
 
+struct CombatLds {
+    uint32_t D[26][WG];                  // damage per target index of the half-item a lane is processing, 4 x u8 per word
+    uint32_t SNAP[24][WG];               // pre-combat snapshot per group: bit31 fights | list-order prefix << 16 | node << 12 | alive mask
+    uint32_t ACC[6][WG];                 // alive units of the fighting groups per (player, node): [p*3 + node/4], 8 bits per node
+    uint32_t TURN[WG], EPI[WG];          // per-env scalars a lane needs when it works on another lane's env
+    uint16_t W[WG * 2 * NN];             // work list of half-items: env lane | node << 6 | attacking player << 10
+};
+
 struct __align__(16) StepLds {
     uint32_t G[24][WG];                  // group words, lane-private columns
     uint32_t NW[12][WG];                 // node words by node ID
-    union {
-        uint32_t D[26][WG];              // combat: damage per target index, 4 x u8 per word
+    union {                              // phases are disjoint in time (one wavefront per workgroup)
+        CombatLds c;
         uint32_t A[24][WG];              // capture: per (player,node) points | units << 16
+        uint32_t R[WG * REC_WORDS];      // observation records, [env][word], odd stride
     } u;
-    uint32_t R[WG * REC_WORDS];          // observation records, [env][word], odd stride
     uint64_t adj[12];
     double   defense[12];
     uint16_t desc[DESC_MAX];
 };
 
-__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
-
-__device__ __forceinline__ uint32_t min12(const uint32_t (&k)[12]) {
-    return umin3(umin3(k[0], k[1], k[2]), umin3(k[3], k[4], k[5]), min(umin3(k[6], k[7], k[8]), umin3(k[9], k[10], k[11])));
-}
+// 12-input sorting network (tools/gen_sort12.py: 42 compare-exchanges, verified with the 0-1 principle)
+#define EVG_SORT12_CES(CE) \
+    CE(0, 1) CE(2, 3) CE(4, 5) CE(6, 7) CE(8, 9) CE(10, 11) CE(0, 2) CE(1, 3) \
+    CE(4, 6) CE(5, 7) CE(8, 10) CE(9, 11) CE(1, 2) CE(5, 6) CE(9, 10) CE(0, 4) \
+    CE(1, 5) CE(2, 6) CE(3, 7) CE(2, 4) CE(3, 5) CE(1, 2) CE(3, 4) CE(5, 6) \
+    CE(9, 10) CE(0, 8) CE(1, 9) CE(2, 10) CE(3, 11) CE(4, 8) CE(5, 9) CE(6, 10) \
+    CE(7, 11) CE(2, 4) CE(3, 5) CE(6, 8) CE(7, 9) CE(1, 2) CE(3, 4) CE(5, 6) \
+    CE(7, 8) CE(9, 10)
 
 // numpy's pairwise summation of a short contiguous float64 vector (np.sum at server.py:481):
 // ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)), then the tail sequentially.
@@ -105,12 +116,13 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     const bool frozen = status != 0;                    // finished, not auto-reset: repeat terminal outputs
     const bool play = valid && !frozen && !observe_only;
     const uint64_t p1nib = T->p1map_nib;
-    const uint32_t env_id = S.env_id_base + (uint32_t)e;
     const int max_turns = T->max_turns;
 
+    const uint32_t abl = io.ablate;         // diagnostic only (EVG_ABLATE): skips phases to price them; 0 in production
     if (play) {
         turn += 1;                                                               // server.py:214
         // ---------------- orders (server.py:218-271)
+        if (!(abl & 1u)) {
         const int4* ap = reinterpret_cast<const int4*>(io.actions) + (size_t)e * 7;
         int4 a[7];
 #pragma unroll
@@ -137,137 +149,194 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
                 L.G[p * 12 + gid][lane] = accept ? nw_ : w;
             }
         }
-
-        // ---------------- combat (server.py:503-654)
-        uint32_t g[24];
-#pragma unroll
-        for (int k = 0; k < 24; ++k) g[k] = L.G[k][lane];                        // pre-combat snapshot
-        uint32_t occ0 = 0, occ1 = 0;
-#pragma unroll
-        for (int k = 0; k < 24; ++k) {
-            const uint32_t w = g[k];
-            const bool elig = (w & G_MASK_M) != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;   // :525
-            const uint32_t bit = (elig ? 1u : 0u) << (w & G_LOC_M);
-            if (k < 12) occ0 |= bit; else occ1 |= bit;
         }
-        uint32_t contested = occ0 & occ1;                                        // :539
+
+    }
+
+    // ---------------- combat (server.py:503-654)
+    // Stage 0 (lane = env): pre-combat snapshot.  A group fights at its node if it is alive and not moving (:525)
+    // and the node holds such groups of both players (:539).  The reference walks node.groups[p] in list order,
+    // which is (arrival stamp, gid) order; target index uid counts alive units along that
+    // order, so each fighting group gets the prefix `base` of alive units listed before it.
+    uint32_t g[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) g[k] = L.G[k][lane];
+    uint32_t occ0 = 0, occ1 = 0;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+        const uint32_t w = g[k];
+        const bool elig = (w & G_MASK_M) != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;
+        const uint32_t bit = (elig ? 1u : 0u) << (w & G_LOC_M);
+        if (k < 12) occ0 |= bit; else occ1 |= bit;
+    }
+    const uint32_t contested = (play && !(abl & 2u)) ? (occ0 & occ1) : 0u;
+    if (__any(contested != 0)) {                      // wave-uniform: skip when none of the 64 envs fights
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            uint32_t key[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const uint32_t w = g[p * 12 + k];
+                const uint32_t mask = (w & G_MASK_M) >> G_MASK_S;
+                const uint32_t elig = (mask != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING) ? 1u : 0u;
+                const uint32_t stamp = (st[(p * 12 + k) >> 2] >> (8 * ((p * 12 + k) & 3))) & 0xFFu;
+                key[k] = (stamp << 21) | ((uint32_t)k << 17) | ((w & G_LOC_M) << 13) | (mask << 1) | elig;
+            }
+#define EVG_CE(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }
+            EVG_SORT12_CES(EVG_CE)
+#undef EVG_CE
+            uint32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {            // list order
+                const uint32_t kk = key[i];
+                const uint32_t gid = (kk >> 17) & 15u, loc = (kk >> 13) & 15u, mask = (kk >> 1) & 0xFFFu;
+                const bool fights = (kk & 1u) && ((contested >> loc) & 1u);
+                const uint32_t idx = loc >> 2, sh = (loc & 3u) * 8;
+                const uint32_t cur = idx == 0 ? a0 : (idx == 1 ? a1 : a2);
+                const uint32_t base = (cur >> sh) & 0xFFu;
+                const uint32_t add = fights ? (uint32_t)__popc(mask) << sh : 0u;
+                a0 += idx == 0 ? add : 0u;
+                a1 += idx == 1 ? add : 0u;
+                a2 += idx == 2 ? add : 0u;
+                L.u.c.SNAP[p * 12 + gid][lane] = fights ? (0x80000000u | (base << 16) | (loc << 12) | mask) : 0u;
+            }
+            L.u.c.ACC[p * 3 + 0][lane] = a0;
+            L.u.c.ACC[p * 3 + 1][lane] = a1;
+            L.u.c.ACC[p * 3 + 2][lane] = a2;
+        }
+        L.u.c.TURN[lane] = (uint32_t)turn;
+        L.u.c.EPI[lane] = episode;
+
+        // Stage 1: wave-wide work list of half-items (env, node, attacking player), by prefix scan over lanes
+        const int nitems = 2 * __popc(contested);
+        int incl = nitems;
+#pragma unroll
+        for (int d = 1; d < WG; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const int total = __shfl(incl, WG - 1);
+        {
+            int off = incl - nitems;
+            uint32_t c = contested;
+            while (c) {
+                const uint32_t node = (uint32_t)__ffs(c) - 1u;
+                c &= c - 1;
+                L.u.c.W[off++] = (uint16_t)((uint32_t)lane | (node << 6));
+                L.u.c.W[off++] = (uint16_t)((uint32_t)lane | (node << 6) | (1u << 10));
+            }
+        }
+        __syncthreads();
+
+        // Stage 2: lanes take half-items round-robin, whichever env they belong to (balanced over the wave).
+        // Half-item (env, node, p): the alive units of p's fighting groups each draw one target among the
+        // q-side's alive units at the node (:549-566); the summed damage is then applied to q (:573-644).
+        // Both half-items of a node read only the snapshot, so the two directions are simultaneous.
         const uint64_t tn0 = T->type_nib[0], tn1 = T->type_nib[1];
         const uint32_t dmg_nib = T->damage_nib, armor_byte = T->armor_byte;
-        while (contested) {
-            const int node = __ffs(contested) - 1;
-            contested &= contested - 1;
-            uint32_t key[2][12];
-            int tot[2] = {0, 0};
+        for (int it = lane; it < total; it += WG) {
+            const uint32_t item = L.u.c.W[it];
+            const int EL = (int)(item & 63u), node = (int)((item >> 6) & 15u), p = (int)(item >> 10), q = 1 - p;
+            const uint64_t tn_p = p ? tn1 : tn0, tn_q = q ? tn1 : tn0;
+            const int tot_q = (int)((L.u.c.ACC[q * 3 + (node >> 2)][EL] >> ((node & 3) * 8)) & 0xFFu);
+            uint32_t pm = 0, qm = 0;
 #pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                const uint32_t w = g[k];
-                const bool member = (w & G_MASK_M) != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING && (int)(w & G_LOC_M) == node;
-                const uint32_t cnt = __popc(w & G_MASK_M);
-                const uint32_t stamp = (st[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                key[k / 12][k % 12] = member ? ((stamp << 8) | ((uint32_t)(k % 12) << 4) | cnt) : 0xFFFFFFFFu;   // list order
-                tot[k / 12] += member ? (int)cnt : 0;
+            for (int k = 0; k < 12; ++k) {
+                const uint32_t sp = L.u.c.SNAP[p * 12 + k][EL], sq = L.u.c.SNAP[q * 12 + k][EL];
+                pm |= ((sp >> 31) && (int)((sp >> 12) & 15u) == node) ? (1u << k) : 0u;
+                qm |= ((sq >> 31) && (int)((sq >> 12) & 15u) == node) ? (1u << k) : 0u;
             }
-            const uint32_t nword = L.NW[node][lane];
-            const int ctrl_by = (int)((nword >> 10) & 3u) - 1;
-            const double ndef = L.defense[node];
+            const int nwords = (tot_q + 3) >> 2;
+            for (int i = 0; i < nwords; ++i) L.u.c.D[i][lane] = 0;
+            const int turn_e = (int)L.u.c.TURN[EL];
+            const uint32_t epi_e = L.u.c.EPI[EL], env_id_e = S.env_id_base + (uint32_t)(e0 + EL);
+            // draw phase
+            while (pm) {
+                const int gid = __ffs(pm) - 1;
+                pm &= pm - 1;
+                const int cnt = __popc(L.u.c.SNAP[p * 12 + gid][EL] & 0xFFFu);
+                const uint32_t type = (uint32_t)((tn_p >> (4 * gid)) & 15u);
+                const uint32_t dmg = (dmg_nib >> (4 * type)) & 15u;
+                for (int b = 0; b * 4 < cnt; ++b) {
+                    const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id_e, epi_e, RNG_COMBAT, (uint32_t)b, turn_e, node, p, gid);
+                    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {                // p attacks q; both sides use the pre-combat snapshot
-                const int q = 1 - p;
-                const uint64_t tn_p = p ? tn1 : tn0, tn_q = q ? tn1 : tn0;
-                const int nwords = (tot[q] + 3) >> 2;
-                for (int i = 0; i < nwords; ++i) L.u.D[i][lane] = 0;
-                // draw phase (:549-566)
-                uint32_t kk[12];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) kk[k] = key[p][k];
-                for (;;) {
-                    const uint32_t m = min12(kk);
-                    if (m == 0xFFFFFFFFu) break;
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) kk[k] = kk[k] == m ? 0xFFFFFFFFu : kk[k];
-                    const int gid = (int)((m >> 4) & 15u), cnt = (int)(m & 15u);
-                    const uint32_t type = (uint32_t)((tn_p >> (4 * gid)) & 15u);
-                    const uint32_t dmg = (dmg_nib >> (4 * type)) & 15u;
-                    for (int b = 0; b * 4 < cnt; ++b) {
-                        const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_COMBAT, (uint32_t)b, turn, node, p, gid);
-                        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (b * 4 + i < cnt) {
-                                const uint32_t uid = __umulhi(xs[i], (uint32_t)tot[q]);            // :562
-                                L.u.D[uid >> 2][lane] += dmg << (8 * (uid & 3u));                  // :563-566
-                            }
+                    for (int i = 0; i < 4; ++i) {
+                        if (b * 4 + i < cnt) {
+                            const uint32_t uid = __umulhi(xs[i], (uint32_t)tot_q);                  // :562
+                            L.u.c.D[uid >> 2][lane] += dmg << (8 * (uid & 3u));                    // :563-566
                         }
                     }
                 }
-                // apply phase (:573-644): uid-th alive unit of the snapshot, groups in list order
+            }
+            // apply phase: uid-th alive unit of the snapshot, groups in list order (prefix `base`)
+            const uint32_t nword = L.NW[node][EL];
+            const int ctrl_by = (int)((nword >> 10) & 3u) - 1;
+            const double ndef = L.defense[node];
+            while (qm) {
+                const int gid = __ffs(qm) - 1;
+                qm &= qm - 1;
+                const uint32_t sq = L.u.c.SNAP[q * 12 + gid][EL];
+                const uint32_t mask = sq & 0xFFFu;
+                int idx = (int)((sq >> 16) & 0xFFu);
+                uint32_t dm[3] = {0, 0, 0}, any = 0;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) kk[k] = key[q][k];
-                int base = 0;
-                for (;;) {
-                    const uint32_t m = min12(kk);
-                    if (m == 0xFFFFFFFFu) break;
+                for (int sl = 0; sl < 12; ++sl) {
+                    if ((mask >> sl) & 1u) {
+                        const uint32_t d = (L.u.c.D[idx >> 2][lane] >> (8 * (idx & 3))) & 0xFFu;
+                        ++idx;
+                        dm[sl >> 2] |= d << (8 * (sl & 3));
+                        any |= d;
+                    }
+                }
+                if (any) {
+                    double* row = S.health + (size_t)(e0 + EL) * (2 * NU) + q * NU + gid * 8;
+                    double h[12];
+                    const double2* r2 = reinterpret_cast<const double2*>(row);
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) kk[k] = kk[k] == m ? 0xFFFFFFFFu : kk[k];
-                    const int gid = (int)((m >> 4) & 15u), cnt = (int)(m & 15u);
-                    const uint32_t w = L.G[q * 12 + gid][lane];
-                    const uint32_t mask = (w & G_MASK_M) >> G_MASK_S;
-                    uint32_t dm[3] = {0, 0, 0}, any = 0;
-                    int idx = base;
+                    for (int sl = 0; sl < 4; ++sl) { const double2 v = r2[sl]; h[2 * sl] = v.x; h[2 * sl + 1] = v.y; }
+                    if (gid == 11) {
 #pragma unroll
-                    for (int s = 0; s < 12; ++s) {
-                        if ((mask >> s) & 1u) {
-                            const uint32_t d = (L.u.D[idx >> 2][lane] >> (8 * (idx & 3))) & 0xFFu;
-                            ++idx;
-                            dm[s >> 2] |= d << (8 * (s & 3));
-                            any |= d;
+                        for (int sl = 4; sl < 6; ++sl) { const double2 v = r2[sl]; h[2 * sl] = v.x; h[2 * sl + 1] = v.y; }
+                    } else {
+                        h[8] = h[9] = h[10] = h[11] = 0.0;
+                    }
+                    const uint32_t type = (uint32_t)((tn_q >> (4 * gid)) & 15u);
+                    const double armor = (double)((armor_byte >> (8 * type)) & 0xFFu);
+                    const double denom = armor + (ctrl_by == q ? ndef : 0.0);                       // :592-597 (fort bonus dead)
+                    uint32_t newmask = mask;
+#pragma unroll
+                    for (int sl = 0; sl < 12; ++sl) {
+                        const uint32_t d = (dm[sl >> 2] >> (8 * (sl & 3))) & 0xFFu;
+                        if (d) {
+                            const double loss = (10.0 * (double)d) / denom;                           // :601
+                            double hv = h[sl] - loss;                                                 // :609
+                            if (hv <= 0.0) { hv = 0.0; newmask &= ~(1u << sl); }                      // :615-618
+                            h[sl] = hv;
                         }
                     }
-                    base += cnt;
-                    if (any) {
-                        double* row = S.health + (size_t)e * (2 * NU) + q * NU + gid * 8;
-                        double h[12];
-                        const double2* r2 = reinterpret_cast<const double2*>(row);
+                    double2* w2 = reinterpret_cast<double2*>(row);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) { const double2 v = r2[s]; h[2 * s] = v.x; h[2 * s + 1] = v.y; }
-                        if (gid == 11) {
+                    for (int sl = 0; sl < 4; ++sl) w2[sl] = make_double2(h[2 * sl], h[2 * sl + 1]);
+                    double sum = np_sum8(h);
+                    if (gid == 11) {
 #pragma unroll
-                            for (int s = 4; s < 6; ++s) { const double2 v = r2[s]; h[2 * s] = v.x; h[2 * s + 1] = v.y; }
-                        } else {
-                            h[8] = h[9] = h[10] = h[11] = 0.0;
-                        }
-                        const uint32_t type = (uint32_t)((tn_q >> (4 * gid)) & 15u);
-                        const double armor = (double)((armor_byte >> (8 * type)) & 0xFFu);
-                        const double denom = armor + (ctrl_by == q ? ndef : 0.0);                   // :592-597 (fort bonus dead)
-                        uint32_t newmask = mask;
-#pragma unroll
-                        for (int s = 0; s < 12; ++s) {
-                            const uint32_t d = (dm[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-                            if (d) {
-                                const double loss = (10.0 * (double)d) / denom;                       // :601
-                                double hv = h[s] - loss;                                              // :609
-                                if (hv <= 0.0) { hv = 0.0; newmask &= ~(1u << s); }                   // :615-618
-                                h[s] = hv;
-                            }
-                        }
-                        double2* w2 = reinterpret_cast<double2*>(row);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) w2[s] = make_double2(h[2 * s], h[2 * s + 1]);
-                        double sum = np_sum8(h);
-                        if (gid == 11) {
-#pragma unroll
-                            for (int s = 4; s < 6; ++s) w2[s] = make_double2(h[2 * s], h[2 * s + 1]);
-                            sum = (((sum + h[8]) + h[9]) + h[10]) + h[11];
-                        }
-                        const int alive = __popc(newmask);
-                        const uint32_t avg = alive ? (uint32_t)(int)(sum / (double)alive) : 0u;      // :491 truncation
-                        L.G[q * 12 + gid][lane] = (w & ~(G_MASK_M | G_AVG_M)) | (newmask << G_MASK_S) | (avg << G_AVG_S);
+                        for (int sl = 4; sl < 6; ++sl) w2[sl] = make_double2(h[2 * sl], h[2 * sl + 1]);
+                        sum = (((sum + h[8]) + h[9]) + h[10]) + h[11];
                     }
+                    const int alive = __popc(newmask);
+                    const uint32_t avg = alive ? (uint32_t)(int)(sum / (double)alive) : 0u;          // :491 truncation
+                    const uint32_t w = L.G[q * 12 + gid][EL];
+                    L.G[q * 12 + gid][EL] = (w & ~(G_MASK_M | G_AVG_M)) | (newmask << G_MASK_S) | (avg << G_AVG_S);
                 }
             }
         }
+        __syncthreads();
+    }
 
+    if (play) {
         // ---------------- movement (server.py:656-706)
+        if (!(abl & 4u))
 #pragma unroll
         for (int k = 0; k < 24; ++k) {
             uint32_t w = L.G[k][lane];
@@ -408,7 +477,8 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     }
 
     // ---------------- observation record (board_state :382-455, player_state :457-501)
-    uint32_t* rec = &L.R[lane * REC_WORDS];
+    __syncthreads();        // all lanes have read their A columns before anyone overwrites the union with records
+    uint32_t* rec = &L.u.R[lane * REC_WORDS];
     if (do_reset) {
         // new episode: state of game_init (server.py:133-209), observation of everglades_env.py:75-116
         turn = 0; status = 0; episode += 1u;
@@ -443,7 +513,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     }
 
     // ---------------- store state (coalesced)
-    if (valid && !observe_only && (play || do_reset)) {
+    if (valid && !observe_only && (play || do_reset) && !(abl & 32u)) {
 #pragma unroll
         for (int k = 0; k < 24; ++k) S.grp[(size_t)k * N + e] = gw[k];
 #pragma unroll
@@ -456,13 +526,14 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     __syncthreads();        // records visible to the whole wave; combat's health stores drained
 
     // ---------------- observation write-out: 64 envs x 2 x 105 elements, 16 bytes per lane, coalesced
-    if (io.obs) {
+    if (io.obs && !(abl & 16u)) {
         constexpr int EP = 16 / (int)sizeof(OT);          // elements per 16-byte vector
         constexpr int U = EP == 2 ? 1 : (EP == 4 ? 2 : 4); // envs per descriptor unit: U*210 % EP == 0
         constexpr int VPU = U * 2 * OBS / EP;              // = 105 vectors per unit
         const int nvec = (WG / U) * VPU;
         const int limit = nvalid * 2 * OBS;
         OT* out = reinterpret_cast<OT*>(io.obs) + (size_t)e0 * (2 * OBS);
+#pragma unroll 4
         for (int v = lane; v < nvec; v += WG) {
             const int unit = v / VPU, r = v - unit * VPU;
             int vals[EP];
@@ -471,7 +542,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
                 const uint32_t d = L.desc[r * EP + j];
                 const int el = unit * U + (int)((d >> 8) & 3u);
                 const uint32_t fld = d & 0xFFu;
-                const uint32_t word = L.R[el * REC_WORDS + (fld >> 1)];
+                const uint32_t word = L.u.R[el * REC_WORDS + (fld >> 1)];
                 const int fv = (int)(int16_t)(word >> (16 * (fld & 1u)));
                 vals[j] = (d & 0x8000u) ? (int)(d & 0x7FFFu) : fv;
             }

@@ -71,7 +71,11 @@ class EvergladesVecEnv(object):
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
-        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+        torch = _torch()
+        try:        # fast path: raw hipStream_t of torch's current stream without building a Stream object
+            return C.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
+        except AttributeError:
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @staticmethod
     def _ptr(t):
@@ -131,6 +135,17 @@ class EvergladesVecEnv(object):
         out = self._actions if out is None else out
         _lib.check(self.L.evg_random_actions(self._h, self._ptr(out), self._stream()))
         return out
+
+    def rollout_random(self, steps, time_kernel=False):
+        """`steps` turns of random-vs-random play driven from native code (evg_rollout_random): per turn the
+        on-device random_actions generator fills self._actions, then the step kernel runs.  Returns the outputs of
+        the last turn like step(); with time_kernel=True also the average step-kernel time in ms (synchronises)."""
+        ms = C.c_float(0.0)
+        _lib.check(self.L.evg_rollout_random(self._h, int(steps), self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
+                                             self._ptr(self.done), self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status),
+                                             C.byref(ms) if time_kernel else None, self._stream()))
+        out = (self.obs, self.reward, self.done, dict(winner=self.winner, scores=self.scores, status=self.status))
+        return out + (float(ms.value),) if time_kernel else out
 
     # ------------------------------------------------------------------ state exchange / stats
     def get_state(self):

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Diagnostic: price the phases of the step kernel by skipping them (EVG_ABLATE bits, read at evg_create).
+bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store.  Not a benchmark."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import everglades_amd as evg
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+for abl in (0, 16, 2, 18, 4, 1, 17, 49, 0):
+    os.environ["EVG_ABLATE"] = str(abl)
+    env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True)
+    env.reset()
+    env.rollout_random(60)
+    res = []
+    for seg in range(3):
+        ms = env.rollout_random(50, time_kernel=True)[-1]
+        res.append(ms * 1e3)
+    torch.cuda.synchronize()
+    print("ablate=%2d  step kernel us at turns 61-110 / 111-160(reset at 150) / 161-210: %s" % (abl, ["%.1f" % r for r in res]), flush=True)
+    env.close()
