@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libevg.so")
+LIB_PATH = os.environ.get("EVG_LIB_PATH") or os.path.join(HERE, "libevg.so")   # override: diagnostic builds only
 
 NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105
 MAX_SCORE = 3700

@@ -49,6 +49,7 @@ struct evg_handle {
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
     uint32_t ablate = 0;                // EVG_ABLATE (diagnostic)
+    unsigned long long* stamps = nullptr;   // diagnostic build only
 };
 
 template <typename Tp>
@@ -163,51 +164,31 @@ static int build_dev_tables(const evg_config* cfg, DevTables* D) {
         D->init_node[n] = (uint32_t)(cs + 512) | ((uint32_t)(cb + 1) << 10);
     }
 
-    // observation record + descriptors (kernel comment "fields")
-    int16_t f[REC_FIELDS];
-    memset(f, 0, sizeof(f));
-    for (int n = 1; n <= NN; ++n) {
-        f[n] = (int16_t)((int)(D->init_node[n] & 0x3FF) - 512);
-        f[11 + n] = (int16_t)(start[1] == n ? NU : 0);
-        f[22 + n] = (int16_t)(start[0] == n ? NU : 0);
-    }
     for (int p = 0; p < NP; ++p)
         for (int g = 0; g < NG; ++g) {
-            const int b = 34 + 4 * (p * NG + g);
-            f[b] = (int16_t)(p == 1 ? t.p1_node_map[start[p]] : start[p]);
-            f[b + 1] = 100; f[b + 2] = 0; f[b + 3] = (int16_t)kGroupSize[g];
+            const int ty = t.group_type[p][g];
+            D->speed_nib[p] |= (uint64_t)t.unit_speed[ty] << (4 * g);
+            D->control_nib[p] |= (uint64_t)t.unit_control[ty] << (4 * g);
+            D->cost_nib[p] |= (uint64_t)t.unit_cost[ty] << (4 * g);
         }
-    for (int w = 0; w < REC_WORDS; ++w) D->reset_rec[w] = (uint32_t)(uint16_t)f[2 * w] | ((uint32_t)(uint16_t)f[2 * w + 1] << 16);
+    for (int i = 1; i <= NN; ++i) D->p1inv_nib |= (uint64_t)i << (4 * t.p1_node_map[i]);
 
-    uint16_t desc1[2 * OBS];
+    // observation of the game_init state (everglades_env.py:158-171 over server.py:382-501)
     for (int p = 0; p < NP; ++p) {
-        uint16_t* d = desc1 + p * OBS;
-        d[0] = 0;                                                                     // turn
+        int16_t* o = D->reset_obs + p * OBS;
+        o[0] = 0;
         for (int i = 1; i <= NN; ++i) {
             const int n = p == 1 ? t.p1_node_map[i] : i;                              // server.py:437-439
-            d[1 + 4 * (i - 1) + 0] = (uint16_t)(0x8000 | ((t.node_resource[n] & EVG_RES_DEFENSE) ? 1 : 0));
-            d[1 + 4 * (i - 1) + 1] = (uint16_t)(0x8000 | ((t.node_resource[n] & EVG_RES_OBSERVE) ? 1 : 0));
-            d[1 + 4 * (i - 1) + 2] = (uint16_t)n;                                     // controlState, sign not mirrored
-            d[1 + 4 * (i - 1) + 3] = (uint16_t)(p == 0 ? 11 + n : 22 + n);            // opposing units listed at the node
+            o[1 + 4 * (i - 1) + 0] = (t.node_resource[n] & EVG_RES_DEFENSE) ? 1 : 0;
+            o[1 + 4 * (i - 1) + 1] = (t.node_resource[n] & EVG_RES_OBSERVE) ? 1 : 0;
+            o[1 + 4 * (i - 1) + 2] = (int16_t)((int)(D->init_node[n] & 0x3FF) - 512);
+            o[1 + 4 * (i - 1) + 3] = (int16_t)(start[1 - p] == n ? NU : 0);
         }
         for (int g = 0; g < NG; ++g) {
-            const int b = 34 + 4 * (p * NG + g);
-            uint16_t* o = d + 45 + 5 * g;
-            o[0] = (uint16_t)b;
-            o[1] = (uint16_t)(0x8000 | t.group_type[p][g]);
-            o[2] = (uint16_t)(b + 1); o[3] = (uint16_t)(b + 2); o[4] = (uint16_t)(b + 3);
+            int16_t* q = o + 45 + 5 * g;
+            q[0] = (int16_t)(p == 1 ? t.p1_node_map[start[p]] : start[p]);
+            q[1] = (int16_t)t.group_type[p][g]; q[2] = 100; q[3] = 0; q[4] = (int16_t)kGroupSize[g];
         }
-    }
-    const int U = cfg->obs_dtype == EVG_OBS_F64 ? 1 : (cfg->obs_dtype == EVG_OBS_F32 ? 2 : 4);
-    D->desc_unit_envs = U;
-    for (int u = 0; u < U; ++u)
-        for (int i = 0; i < 2 * OBS; ++i) {
-            const uint16_t d = desc1[i];
-            D->obs_desc[u * 2 * OBS + i] = (d & 0x8000) ? d : (uint16_t)(d | (u << 8));
-        }
-    for (int i = 0; i < 2 * OBS; ++i) {
-        const uint16_t d = desc1[i];
-        D->reset_obs[i] = (d & 0x8000) ? (int16_t)(d & 0x7FFF) : f[d & 0xFF];
     }
     return EVG_OK;
 }
@@ -257,6 +238,10 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (!rc) rc = dev_alloc(h, &h->d_tables, 1);
     if (rc) { evg_destroy(h); return rc; }
     S.T = h->d_tables;
+#ifdef EVG_STAMPS
+    if (!rc) rc = dev_alloc(h, &h->stamps, (size_t)((cfg->num_envs + WG / 2 - 1) / (WG / 2)) * 16);
+    if (rc) { evg_destroy(h); return rc; }
+#endif
     hipError_t e = hipMemcpy(h->d_tables, &h->host_tables, sizeof(DevTables), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(S.episode, 0, N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(S.fin_ret, 0, 2 * N * sizeof(float));
@@ -302,7 +287,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, h->ablate};
+    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, h->stamps, h->ablate};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -311,7 +296,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
 int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0};
+    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -338,7 +323,7 @@ int evg_rollout_random(evg_handle* h, int steps, int32_t* actions_buf, void* obs
             h->events.push_back(ev);
         }
     }
-    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, h->ablate};
+    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, h->stamps, h->ablate};
     for (int i = 0; i < steps; ++i) {
         int rc = launch_random_actions(h->S, actions_buf, stream);
         if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -460,6 +445,16 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
     if (totals) HIP_TRY(hipMemcpy(totals, h->S.totals, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return EVG_OK;
 }
+
+#ifdef EVG_STAMPS
+/* diagnostic build only: per-workgroup s_memtime stamps of the last step launch, [blocks][16] */
+int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->stamps, (size_t)((h->S.N + WG / 2 - 1) / (WG / 2)) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return EVG_OK;
+}
+#endif
 
 int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");

@@ -26,9 +26,7 @@ namespace evg {
 
 constexpr int NP = 2, NG = 12, NN = 11, NU = 100, NA = 7, OBS = 105;
 constexpr int WG = 64;                    // one wavefront per workgroup, one env per lane
-constexpr int REC_WORDS = 65;             // observation record: 130 int16 fields per env
-constexpr int REC_FIELDS = 130;
-constexpr int DESC_MAX = 840;             // descriptors for a unit of up to 4 envs (i16 obs)
+constexpr int OBS2 = 2 * OBS;             // both players' observations of one env, contiguous in the output
 
 // group word fields
 constexpr uint32_t G_LOC_M = 0xFu, G_DEST_S = 4, G_DIST_S = 8, G_MODE_S = 11, G_MASK_S = 13, G_AVG_S = 25;
@@ -44,6 +42,8 @@ struct DevTables {
     int32_t  resource[12];
     uint64_t p1map_nib;          // nibble i = p1_node_map[i]
     uint64_t type_nib[2];        // nibble k = unit type of group k
+    uint64_t speed_nib[2], control_nib[2], cost_nib[2];   // nibble k = speed / control / cost of group k's unit type
+    uint64_t p1inv_nib;          // nibble n = slot of p1's board view that shows node n (inverse of p1_node_map)
     uint32_t damage_nib;         // nibble t = damage of unit type t
     uint32_t armor_byte;         // byte t   = health ("armor") of unit type t
     int32_t  unit_speed[4], unit_control[4], unit_cost[4];
@@ -51,10 +51,7 @@ struct DevTables {
     int32_t  max_turns;
     uint32_t init_grp[24];       // state right after game_init (server.py:133-209)
     uint32_t init_node[12];
-    uint32_t reset_rec[REC_WORDS];   // observation record of that state
     int16_t  reset_obs[2 * OBS];     // and the observation itself
-    int32_t  desc_unit_envs;     // U: envs per descriptor unit (f64 1, f32 2, i16 4)
-    uint16_t obs_desc[DESC_MAX]; // per output element: bit15 const | value, else field | env_in_unit << 8
 };
 
 struct DevState {
@@ -84,6 +81,7 @@ struct StepIO {
     int32_t*  scores;
     uint8_t*  status;
     int32_t   observe_only;      // 1: only (re)build observations from the current state
+    unsigned long long* stamps;  // diagnostic build (EVG_STAMPS) only, else NULL
     uint32_t  ablate;            // diagnostic: bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
 };
 

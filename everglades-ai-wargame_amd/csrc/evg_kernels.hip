@@ -20,25 +20,42 @@
 
 namespace evg {
 
+// Diagnostic build only (make stamps -> libevg_stamps.so): lane 0 of every wave stores s_memtime at phase
+// boundaries into a debug buffer of its own; the production library contains no stamp.
+#ifdef EVG_STAMPS
+#define STAMP(i)                                                                        \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        const unsigned long long t_ = clock64();                                        \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (lane == 0 && io.stamps) io.stamps[(size_t)blockIdx.x * 16 + (i)] = t_;      \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
+constexpr int EPW = WG / 2;               // envs per wavefront: lane = 2 * env_slot + player
+constexpr int DP_CAP = 1536;              // words of the shared damage pool (worst case of 16 envs: 1056)
+
 struct CombatLds {
-    uint32_t D[26][WG];                  // damage per target index of the half-item a lane is processing, 4 x u8 per word
-    uint32_t SNAP[24][WG];               // pre-combat snapshot per group: bit31 fights | list-order prefix << 16 | node << 12 | alive mask
-    uint32_t ACC[6][WG];                 // alive units of the fighting groups per (player, node): [p*3 + node/4], 8 bits per node
-    uint32_t TURN[WG], EPI[WG];          // per-env scalars a lane needs when it works on another lane's env
-    uint16_t W[WG * 2 * NN];             // work list of half-items: env lane | node << 6 | attacking player << 10
+    uint32_t SNAP[12][WG];               // pre-combat snapshot of the lane's own group k:
+                                         //   bit31 fights | list-order prefix of alive units << 16 | node << 12 | alive mask
+    uint32_t FS[12][WG];                 // the lane's own side at node n: alive fighting units << 16 | word offset of its damage bytes in DP
+    uint32_t TURN[WG], EPI[WG];          // per-env scalars for lanes that work on another env's item
+    uint16_t W[WG * 12];                 // work list of fighting groups: owner lane | gid << 6
+    uint32_t DP[DP_CAP];                 // damage pool: one byte per targeted unit index, filled with LDS atomics
 };
 
 struct __align__(16) StepLds {
-    uint32_t G[24][WG];                  // group words, lane-private columns
-    uint32_t NW[12][WG];                 // node words by node ID
+    uint32_t G[12][WG];                  // group words, lane-private columns (lane = env slot, player)
+    uint32_t NW[12][EPW];                // node words by node ID, one column per env
     union {                              // phases are disjoint in time (one wavefront per workgroup)
         CombatLds c;
-        uint32_t A[24][WG];              // capture: per (player,node) points | units << 16
-        uint32_t R[WG * REC_WORDS];      // observation records, [env][word], odd stride
+        uint32_t A[12][WG];              // per (own side, node): capture points | units listed << 16
+        int16_t  O[WG * OBS];            // observations of the wave's 32 envs, already in output order [env][player][105]
     } u;
     uint64_t adj[12];
     double   defense[12];
-    uint16_t desc[DESC_MAX];
 };
 
 // 12-input sorting network (tools/gen_sort12.py: 42 compare-exchanges, verified with the 0-1 principle)
@@ -76,221 +93,243 @@ __device__ __forceinline__ void store_obs_vec<int16_t>(int16_t* dst, const int (
     *reinterpret_cast<uint4*>(dst) = o;
 }
 
+__device__ __forceinline__ int xchg1(int v) { return __shfl_xor(v, 1); }     // value of the other player's lane
+
 // ---------------------------------------------------------------------------------------------
-// fused env-step
+// fused env-step: lane = (env slot, player); 32 envs per wavefront
 // ---------------------------------------------------------------------------------------------
 template <typename OT>
 __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     __shared__ StepLds L;
     const int lane = threadIdx.x;
-    const int e0 = blockIdx.x * WG;
-    const int nvalid = min(WG, S.N - e0);
-    const bool valid = lane < nvalid;
-    const int e = valid ? e0 + lane : e0;
+    const int E = lane >> 1, P = lane & 1;
+    const int e0 = blockIdx.x * EPW;
+    const int nvalid = min(EPW, S.N - e0);
+    const bool valid = E < nvalid;
+    const int e = valid ? e0 + E : e0;
     const size_t N = (size_t)S.N;
     const DevTables* __restrict__ T = S.T;
 
-    // ---- stage constant tables in LDS
+    STAMP(0);
+    // ---- constant tables: adjacency/defense to LDS (indexed per lane), the rest into scalar registers
     if (lane < 12) {
         L.adj[lane] = T->adj_row[lane];
         L.defense[lane] = T->defense[lane];
     }
-    for (int i = lane; i < DESC_MAX / 2; i += WG)
-        reinterpret_cast<uint32_t*>(L.desc)[i] = reinterpret_cast<const uint32_t*>(T->obs_desc)[i];
+    const uint64_t p1nib = T->p1map_nib;
+    const uint64_t spd_n = P ? T->speed_nib[1] : T->speed_nib[0];
+    const uint64_t ctl_n = P ? T->control_nib[1] : T->control_nib[0];
+    const uint64_t cst_n = P ? T->cost_nib[1] : T->cost_nib[0];
+    const uint64_t typ_n = P ? T->type_nib[1] : T->type_nib[0];
+    const int max_turns = T->max_turns;
 
-    // ---- load state (coalesced, env fastest)
+    // ---- load state (env fastest; the two player rows of a group index interleave across lanes)
     const uint32_t envw = S.env[e];
     int turn = (int)(envw & 0xFFu);
     int status = (int)((envw >> 8) & 3u);
     uint32_t episode = S.episode[e];
-    uint32_t st[6];
+    uint32_t st[3];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) st[j] = S.stamp[(size_t)j * N + e];
+    for (int j = 0; j < 3; ++j) st[j] = S.stamp[(size_t)(P * 3 + j) * N + e];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) L.G[k][lane] = S.grp[(size_t)k * N + e];
+    for (int k = 0; k < 12; ++k) L.G[k][lane] = S.grp[(size_t)(P * 12 + k) * N + e];
 #pragma unroll
-    for (int n = 1; n <= NN; ++n) L.NW[n][lane] = S.node[(size_t)(n - 1) * N + e];
+    for (int j = 0; j < 6; ++j) {                       // player 0 lane: nodes 1..6, player 1 lane: nodes 7..11
+        const int n = P ? 7 + j : 1 + j;
+        if (n <= NN) L.NW[n][E] = S.node[(size_t)(n - 1) * N + e];
+    }
     __syncthreads();
+    STAMP(1);
 
     const bool observe_only = io.observe_only != 0;
     const bool frozen = status != 0;                    // finished, not auto-reset: repeat terminal outputs
     const bool play = valid && !frozen && !observe_only;
-    const uint64_t p1nib = T->p1map_nib;
-    const int max_turns = T->max_turns;
+    const uint32_t abl = io.ablate;                     // diagnostic only (EVG_ABLATE); 0 in production
 
-    const uint32_t abl = io.ablate;         // diagnostic only (EVG_ABLATE): skips phases to price them; 0 in production
     if (play) {
         turn += 1;                                                               // server.py:214
-        // ---------------- orders (server.py:218-271)
+        // ---------------- orders of this lane's player (server.py:218-271)
         if (!(abl & 1u)) {
-        const int4* ap = reinterpret_cast<const int4*>(io.actions) + (size_t)e * 7;
-        int4 a[7];
+            const int2* ap = reinterpret_cast<const int2*>(io.actions) + ((size_t)e * 2 + P) * NA;
+            int2 a[NA];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) a[j] = ap[j];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
+            for (int i = 0; i < NA; ++i) a[i] = ap[i];
             uint32_t used = 0;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int r = p * NA + i;
-                int gid = (r & 1) ? a[r >> 1].z : a[r >> 1].x;
-                int nid = (r & 1) ? a[r >> 1].w : a[r >> 1].y;
+                int gid = a[i].x, nid = a[i].y;
                 const bool ok = (uint32_t)gid < 12u && (uint32_t)nid < 12u;     // build-defined domain
                 gid = ok ? gid : 0;
                 nid = ok ? nid : 0;
-                if (p == 1) nid = (int)((p1nib >> (4 * nid)) & 15u);             // :233-234
-                const uint32_t w = L.G[p * 12 + gid][lane];
+                nid = P ? (int)((p1nib >> (4 * nid)) & 15u) : nid;               // :233-234
+                const uint32_t w = L.G[gid][lane];
                 const int loc = (int)(w & G_LOC_M);
                 const uint32_t d = (uint32_t)((L.adj[loc] >> (4 * nid)) & 15u);  // test3 + distance, :245-250
                 const bool accept = ok && !((used >> gid) & 1u) && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING && d != 0;
                 used |= (accept ? 1u : 0u) << gid;
                 const uint32_t nw_ = (w & ~(G_DEST_M | G_DIST_M | G_MODE_M)) | ((uint32_t)nid << G_DEST_S) | (d << G_DIST_S) |
                                      (MODE_READY << G_MODE_S);                   // :267-270
-                L.G[p * 12 + gid][lane] = accept ? nw_ : w;
+                L.G[gid][lane] = accept ? nw_ : w;
             }
         }
-        }
-
     }
+    STAMP(2);
 
     // ---------------- combat (server.py:503-654)
-    // Stage 0 (lane = env): pre-combat snapshot.  A group fights at its node if it is alive and not moving (:525)
-    // and the node holds such groups of both players (:539).  The reference walks node.groups[p] in list order,
-    // which is (arrival stamp, gid) order; target index uid counts alive units along that
-    // order, so each fighting group gets the prefix `base` of alive units listed before it.
-    uint32_t g[24];
+    // Stage 0 (lane = env side): pre-combat snapshot.  A group fights at its node if it is alive and not moving
+    // (:525) and the node holds such groups of both players (:539).  The reference walks node.groups[p] in list
+    // order, which is (arrival stamp, gid) order; the target index uid counts alive units
+    // along that order, so each fighting group gets the prefix `base` of alive units listed before it.
+    uint32_t g[12];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) g[k] = L.G[k][lane];
-    uint32_t occ0 = 0, occ1 = 0;
+    for (int k = 0; k < 12; ++k) g[k] = L.G[k][lane];
+    uint32_t occ = 0;
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < 12; ++k) {
         const uint32_t w = g[k];
         const bool elig = (w & G_MASK_M) != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;
-        const uint32_t bit = (elig ? 1u : 0u) << (w & G_LOC_M);
-        if (k < 12) occ0 |= bit; else occ1 |= bit;
+        occ |= (elig ? 1u : 0u) << (w & G_LOC_M);
     }
-    const uint32_t contested = (play && !(abl & 2u)) ? (occ0 & occ1) : 0u;
-    if (__any(contested != 0)) {                      // wave-uniform: skip when none of the 64 envs fights
+    const uint32_t contested = (play && !(abl & 2u)) ? (occ & (uint32_t)xchg1((int)occ)) : 0u;
+    if (__any(contested != 0)) {                          // wave-uniform: skip when none of the 32 envs fights
+        uint32_t key[12];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            uint32_t key[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const uint32_t w = g[p * 12 + k];
-                const uint32_t mask = (w & G_MASK_M) >> G_MASK_S;
-                const uint32_t elig = (mask != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING) ? 1u : 0u;
-                const uint32_t stamp = (st[(p * 12 + k) >> 2] >> (8 * ((p * 12 + k) & 3))) & 0xFFu;
-                key[k] = (stamp << 21) | ((uint32_t)k << 17) | ((w & G_LOC_M) << 13) | (mask << 1) | elig;
-            }
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t w = g[k];
+            const uint32_t mask = (w & G_MASK_M) >> G_MASK_S;
+            const uint32_t elig = (mask != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING) ? 1u : 0u;
+            const uint32_t stamp = (st[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            key[k] = (stamp << 21) | ((uint32_t)k << 17) | ((w & G_LOC_M) << 13) | (mask << 1) | elig;
+        }
 #define EVG_CE(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }
-            EVG_SORT12_CES(EVG_CE)
+        EVG_SORT12_CES(EVG_CE)
 #undef EVG_CE
-            uint32_t a0 = 0, a1 = 0, a2 = 0;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, fmask = 0;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {            // list order
-                const uint32_t kk = key[i];
-                const uint32_t gid = (kk >> 17) & 15u, loc = (kk >> 13) & 15u, mask = (kk >> 1) & 0xFFFu;
-                const bool fights = (kk & 1u) && ((contested >> loc) & 1u);
-                const uint32_t idx = loc >> 2, sh = (loc & 3u) * 8;
-                const uint32_t cur = idx == 0 ? a0 : (idx == 1 ? a1 : a2);
-                const uint32_t base = (cur >> sh) & 0xFFu;
-                const uint32_t add = fights ? (uint32_t)__popc(mask) << sh : 0u;
-                a0 += idx == 0 ? add : 0u;
-                a1 += idx == 1 ? add : 0u;
-                a2 += idx == 2 ? add : 0u;
-                L.u.c.SNAP[p * 12 + gid][lane] = fights ? (0x80000000u | (base << 16) | (loc << 12) | mask) : 0u;
-            }
-            L.u.c.ACC[p * 3 + 0][lane] = a0;
-            L.u.c.ACC[p * 3 + 1][lane] = a1;
-            L.u.c.ACC[p * 3 + 2][lane] = a2;
+        for (int i = 0; i < 12; ++i) {                // list order
+            const uint32_t kk = key[i];
+            const uint32_t gid = (kk >> 17) & 15u, loc = (kk >> 13) & 15u, mask = (kk >> 1) & 0xFFFu;
+            const bool fights = (kk & 1u) && ((contested >> loc) & 1u);
+            const uint32_t idx = loc >> 2, sh = (loc & 3u) * 8;
+            const uint32_t cur = idx == 0 ? a0 : (idx == 1 ? a1 : a2);
+            const uint32_t base = (cur >> sh) & 0xFFu;
+            const uint32_t add = fights ? (uint32_t)__popc(mask) << sh : 0u;
+            a0 += idx == 0 ? add : 0u;
+            a1 += idx == 1 ? add : 0u;
+            a2 += idx == 2 ? add : 0u;
+            fmask |= (fights ? 1u : 0u) << gid;
+            L.u.c.SNAP[gid][lane] = fights ? (0x80000000u | (base << 16) | (loc << 12) | mask) : 0u;
         }
         L.u.c.TURN[lane] = (uint32_t)turn;
         L.u.c.EPI[lane] = episode;
-
-        // Stage 1: wave-wide work list of half-items (env, node, attacking player), by prefix scan over lanes
-        const int nitems = 2 * __popc(contested);
-        int incl = nitems;
-#pragma unroll
-        for (int d = 1; d < WG; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        const int total = __shfl(incl, WG - 1);
+        // damage bytes this side needs: one per alive fighting unit, rounded up to a word per node
+        int ndw = 0;
         {
-            int off = incl - nitems;
             uint32_t c = contested;
             while (c) {
-                const uint32_t node = (uint32_t)__ffs(c) - 1u;
+                const uint32_t n = (uint32_t)__ffs(c) - 1u;
                 c &= c - 1;
-                L.u.c.W[off++] = (uint16_t)((uint32_t)lane | (node << 6));
-                L.u.c.W[off++] = (uint16_t)((uint32_t)lane | (node << 6) | (1u << 10));
+                const uint32_t aw = (n >> 2) == 0 ? a0 : ((n >> 2) == 1 ? a1 : a2);
+                ndw += (int)((((aw >> ((n & 3u) * 8)) & 0xFFu) + 3u) >> 2);
             }
         }
-        __syncthreads();
+        STAMP(3);
 
-        // Stage 2: lanes take half-items round-robin, whichever env they belong to (balanced over the wave).
-        // Half-item (env, node, p): the alive units of p's fighting groups each draw one target among the
-        // q-side's alive units at the node (:549-566); the summed damage is then applied to q (:573-644).
-        // Both half-items of a node read only the snapshot, so the two directions are simultaneous.
-        const uint64_t tn0 = T->type_nib[0], tn1 = T->type_nib[1];
-        const uint32_t dmg_nib = T->damage_nib, armor_byte = T->armor_byte;
-        for (int it = lane; it < total; it += WG) {
-            const uint32_t item = L.u.c.W[it];
-            const int EL = (int)(item & 63u), node = (int)((item >> 6) & 15u), p = (int)(item >> 10), q = 1 - p;
-            const uint64_t tn_p = p ? tn1 : tn0, tn_q = q ? tn1 : tn0;
-            const int tot_q = (int)((L.u.c.ACC[q * 3 + (node >> 2)][EL] >> ((node & 3) * 8)) & 0xFFu);
-            uint32_t pm = 0, qm = 0;
+        // Stage 1: wave-wide work list (one item per fighting group) and damage-pool layout, by prefix scan
+        const int nfight = __popc(fmask);
+        int incl_i = nfight, incl_d = ndw;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const uint32_t sp = L.u.c.SNAP[p * 12 + k][EL], sq = L.u.c.SNAP[q * 12 + k][EL];
-                pm |= ((sp >> 31) && (int)((sp >> 12) & 15u) == node) ? (1u << k) : 0u;
-                qm |= ((sq >> 31) && (int)((sq >> 12) & 15u) == node) ? (1u << k) : 0u;
+        for (int d = 1; d < WG; d <<= 1) {
+            const int ti = __shfl_up(incl_i, d), td = __shfl_up(incl_d, d);
+            if (lane >= d) { incl_i += ti; incl_d += td; }
+        }
+        const int excl_i = incl_i - nfight, excl_d = incl_d - ndw;
+        const int tot_i = __shfl(incl_i, WG - 1), tot_d = __shfl(incl_d, WG - 1);
+        const int mid_i = __shfl(excl_i, WG / 2), mid_d = __shfl(excl_d, WG / 2);
+        // the pool holds every fight of the wave in the common case; otherwise two passes of 16 envs each
+        const int npass = tot_d <= DP_CAP ? 1 : 2;
+        const uint32_t dmg_nib = T->damage_nib, armor_byte = T->armor_byte;
+        for (int ps = 0; ps < npass; ++ps) {
+            const bool inpass = npass == 1 || (lane >> 5) == ps;
+            const int ref_i = (npass == 2 && ps == 1) ? mid_i : 0, ref_d = (npass == 2 && ps == 1) ? mid_d : 0;
+            const int end_i = (npass == 2 && ps == 0) ? mid_i : tot_i, end_d = (npass == 2 && ps == 0) ? mid_d : tot_d;
+            const int nitems = end_i - ref_i, ndwords = end_d - ref_d;
+            if (inpass) {
+                int wi = excl_i - ref_i;
+                uint32_t f = fmask;
+                while (f) {
+                    const uint32_t gid = (uint32_t)__ffs(f) - 1u;
+                    f &= f - 1;
+                    L.u.c.W[wi++] = (uint16_t)((uint32_t)lane | (gid << 6));
+                }
+                int doff = excl_d - ref_d;
+                uint32_t c = contested;
+                while (c) {
+                    const uint32_t n = (uint32_t)__ffs(c) - 1u;
+                    c &= c - 1;
+                    const uint32_t aw = (n >> 2) == 0 ? a0 : ((n >> 2) == 1 ? a1 : a2);
+                    const uint32_t tn = (aw >> ((n & 3u) * 8)) & 0xFFu;
+                    L.u.c.FS[n][lane] = (tn << 16) | (uint32_t)doff;
+                    doff += (int)((tn + 3u) >> 2);
+                }
             }
-            const int nwords = (tot_q + 3) >> 2;
-            for (int i = 0; i < nwords; ++i) L.u.c.D[i][lane] = 0;
-            const int turn_e = (int)L.u.c.TURN[EL];
-            const uint32_t epi_e = L.u.c.EPI[EL], env_id_e = S.env_id_base + (uint32_t)(e0 + EL);
-            // draw phase
-            while (pm) {
-                const int gid = __ffs(pm) - 1;
-                pm &= pm - 1;
-                const int cnt = __popc(L.u.c.SNAP[p * 12 + gid][EL] & 0xFFFu);
-                const uint32_t type = (uint32_t)((tn_p >> (4 * gid)) & 15u);
+            for (int i = lane; i < ndwords; i += WG) L.u.c.DP[i] = 0;
+            __syncthreads();
+            STAMP(4);
+
+            // Phase A (:549-566): one lane per fighting group; each of its alive units draws one target among the
+            // opposing side's alive fighting units at the node; damage accumulates in the pool (LDS atomics,
+            // integer and order-free, hence deterministic)
+            for (int it = lane; it < nitems; it += WG) {
+                const uint32_t item = L.u.c.W[it];
+                const int SL = (int)(item & 63u), gid = (int)(item >> 6), side = SL & 1;
+                const uint32_t sp = L.u.c.SNAP[gid][SL];
+                const int node = (int)((sp >> 12) & 15u), cnt = __popc(sp & 0xFFFu);
+                const uint32_t fso = L.u.c.FS[node][SL ^ 1];
+                const uint32_t tot_o = fso >> 16, doff_o = fso & 0xFFFFu;
+                const uint64_t tn_s = side ? T->type_nib[1] : T->type_nib[0];
+                const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
                 const uint32_t dmg = (dmg_nib >> (4 * type)) & 15u;
+                const int turn_e = (int)L.u.c.TURN[SL];
+                const uint32_t epi_e = L.u.c.EPI[SL], env_id_e = S.env_id_base + (uint32_t)(e0 + (SL >> 1));
                 for (int b = 0; b * 4 < cnt; ++b) {
-                    const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id_e, epi_e, RNG_COMBAT, (uint32_t)b, turn_e, node, p, gid);
+                    const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id_e, epi_e, RNG_COMBAT, (uint32_t)b, turn_e, node, side, gid);
                     const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (b * 4 + i < cnt) {
-                            const uint32_t uid = __umulhi(xs[i], (uint32_t)tot_q);                  // :562
-                            L.u.c.D[uid >> 2][lane] += dmg << (8 * (uid & 3u));                    // :563-566
+                            const uint32_t uid = __umulhi(xs[i], tot_o);                                // :562
+                            atomicAdd(&L.u.c.DP[doff_o + (uid >> 2)], dmg << (8 * (uid & 3u)));         // :563-566
                         }
                     }
                 }
             }
-            // apply phase: uid-th alive unit of the snapshot, groups in list order (prefix `base`)
-            const uint32_t nword = L.NW[node][EL];
-            const int ctrl_by = (int)((nword >> 10) & 3u) - 1;
-            const double ndef = L.defense[node];
-            while (qm) {
-                const int gid = __ffs(qm) - 1;
-                qm &= qm - 1;
-                const uint32_t sq = L.u.c.SNAP[q * 12 + gid][EL];
-                const uint32_t mask = sq & 0xFFFu;
-                int idx = (int)((sq >> 16) & 0xFFu);
+            __syncthreads();
+            STAMP(5);
+
+            // Phase B (:573-644): one lane per fighting group; the uid-th alive unit of the snapshot (list-order
+            // prefix + rank among the group's alive slots) takes its summed damage.  Both directions read only
+            // the snapshot and the pool, so they are simultaneous like in the reference.
+            for (int it = lane; it < nitems; it += WG) {
+                const uint32_t item = L.u.c.W[it];
+                const int SL = (int)(item & 63u), gid = (int)(item >> 6), side = SL & 1;
+                const uint32_t sp = L.u.c.SNAP[gid][SL];
+                const int node = (int)((sp >> 12) & 15u);
+                const uint32_t mask = sp & 0xFFFu;
+                const uint32_t doff = L.u.c.FS[node][SL] & 0xFFFFu;
+                int idx = (int)((sp >> 16) & 0xFFu);
                 uint32_t dm[3] = {0, 0, 0}, any = 0;
 #pragma unroll
                 for (int sl = 0; sl < 12; ++sl) {
                     if ((mask >> sl) & 1u) {
-                        const uint32_t d = (L.u.c.D[idx >> 2][lane] >> (8 * (idx & 3))) & 0xFFu;
+                        const uint32_t d = (L.u.c.DP[doff + (idx >> 2)] >> (8 * (idx & 3))) & 0xFFu;
                         ++idx;
                         dm[sl >> 2] |= d << (8 * (sl & 3));
                         any |= d;
                     }
                 }
                 if (any) {
-                    double* row = S.health + (size_t)(e0 + EL) * (2 * NU) + q * NU + gid * 8;
+                    double* row = S.health + (size_t)(e0 + (SL >> 1)) * (2 * NU) + side * NU + gid * 8;
                     double h[12];
                     const double2* r2 = reinterpret_cast<const double2*>(row);
 #pragma unroll
@@ -301,9 +340,11 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
                     } else {
                         h[8] = h[9] = h[10] = h[11] = 0.0;
                     }
-                    const uint32_t type = (uint32_t)((tn_q >> (4 * gid)) & 15u);
+                    const uint64_t tn_s = side ? T->type_nib[1] : T->type_nib[0];
+                    const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
                     const double armor = (double)((armor_byte >> (8 * type)) & 0xFFu);
-                    const double denom = armor + (ctrl_by == q ? ndef : 0.0);                       // :592-597 (fort bonus dead)
+                    const int ctrl_by = (int)((L.NW[node][SL >> 1] >> 10) & 3u) - 1;
+                    const double denom = armor + (ctrl_by == side ? L.defense[node] : 0.0);          // :592-597 (fort bonus dead)
                     uint32_t newmask = mask;
 #pragma unroll
                     for (int sl = 0; sl < 12; ++sl) {
@@ -326,107 +367,110 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
                     }
                     const int alive = __popc(newmask);
                     const uint32_t avg = alive ? (uint32_t)(int)(sum / (double)alive) : 0u;          // :491 truncation
-                    const uint32_t w = L.G[q * 12 + gid][EL];
-                    L.G[q * 12 + gid][EL] = (w & ~(G_MASK_M | G_AVG_M)) | (newmask << G_MASK_S) | (avg << G_AVG_S);
+                    const uint32_t w = L.G[gid][SL];
+                    L.G[gid][SL] = (w & ~(G_MASK_M | G_AVG_M)) | (newmask << G_MASK_S) | (avg << G_AVG_S);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
+    STAMP(6);
 
-    if (play) {
-        // ---------------- movement (server.py:656-706)
-        if (!(abl & 4u))
+    // ---------------- movement of this lane's groups (server.py:656-706), branch-free
+    uint32_t gw[12];
 #pragma unroll
-        for (int k = 0; k < 24; ++k) {
-            uint32_t w = L.G[k][lane];
+    for (int k = 0; k < 12; ++k) gw[k] = L.G[k][lane];
+    if (play && !(abl & 4u)) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t w = gw[k];
             const uint32_t mode = (w & G_MODE_M) >> G_MODE_S;
-            if ((w & G_MASK_M) != 0) {                                            // not destroyed, :663
-                if (mode == MODE_READY) {
-                    w = (w & ~G_MODE_M) | (MODE_MOVING << G_MODE_S);              // :664-667
-                } else if (mode == MODE_MOVING) {
-                    const int type = T->group_type[k / 12][k % 12];
-                    const int nd = (int)((w & G_DIST_M) >> G_DIST_S) - T->unit_speed[type];   // :671
-                    if (nd <= 0) {                                                // arrived, :678-695
-                        const uint32_t dest = (w & G_DEST_M) >> G_DEST_S;
-                        w = (w & ~(G_LOC_M | G_DEST_M | G_DIST_M | G_MODE_M)) | dest;
-                        st[k >> 2] = (st[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)turn << (8 * (k & 3)));
-                    } else {
-                        w = (w & ~G_DIST_M) | ((uint32_t)nd << G_DIST_S);
+            const bool alive = (w & G_MASK_M) != 0;                                    // not destroyed, :663
+            const int nd = (int)((w & G_DIST_M) >> G_DIST_S) - (int)((spd_n >> (4 * k)) & 15u);   // :671
+            const bool arrive = alive && mode == MODE_MOVING && nd <= 0;               // :678-695
+            const uint32_t w_ready = (w & ~G_MODE_M) | (MODE_MOVING << G_MODE_S);      // :664-667
+            const uint32_t w_arrive = (w & ~(G_LOC_M | G_DEST_M | G_DIST_M | G_MODE_M)) | ((w & G_DEST_M) >> G_DEST_S);
+            const uint32_t w_transit = (w & ~G_DIST_M) | ((uint32_t)(nd & 7) << G_DIST_S);
+            uint32_t nw_ = w;
+            nw_ = (alive && mode == MODE_READY) ? w_ready : nw_;
+            nw_ = (alive && mode == MODE_MOVING) ? (arrive ? w_arrive : w_transit) : nw_;
+            const uint32_t sh = 8 * (k & 3);
+            st[k >> 2] = arrive ? ((st[k >> 2] & ~(0xFFu << sh)) | ((uint32_t)turn << sh)) : st[k >> 2];
+            gw[k] = nw_;
+        }
+    }
+    STAMP(7);
+
+    // ---------------- per-node aggregates of this side (post-movement): capture points | units listed << 16
+#pragma unroll
+    for (int n = 0; n < 12; ++n) L.u.A[n][lane] = 0;
+    int my_unit_score = 0, my_alive = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const uint32_t w = gw[k];
+        const int cnt = __popc(w & G_MASK_M);
+        const bool elig = ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;                          // :720
+        const uint32_t ctl = (uint32_t)((ctl_n >> (4 * k)) & 15u);
+        const uint32_t add = (elig ? (uint32_t)cnt * ctl : 0u) | ((uint32_t)cnt << 16);
+        if (cnt) atomicAdd(&L.u.A[w & G_LOC_M][lane], add);                                     // ds_add_u32
+        my_unit_score += cnt * (int)((cst_n >> (4 * k)) & 15u);                                 // :315-317
+        my_alive += cnt;
+    }
+    __syncthreads();
+
+    // ---------------- capture (server.py:708-767) and node scores (:297-310): the pair splits the nodes
+    int part0 = 0, part1 = 0;          // score contributions of this lane's nodes to player 0 / player 1
+    int base_cap = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int n = P ? 7 + j : 1 + j;
+        if (n <= NN) {
+            const uint32_t a0w = L.u.A[n][lane & ~1], a1w = L.u.A[n][lane | 1];
+            uint32_t nword = L.NW[n][E];
+            int cs = (int)(nword & 0x3FFu) - 512;
+            int cb = (int)((nword >> 10) & 3u) - 1;
+            const int cp = P ? T->control_points[(7 + j) % 12] : T->control_points[1 + j];
+            const int ts = P ? T->team_start[(7 + j) % 12] : T->team_start[1 + j];
+            if (play) {
+                const int pts0 = (int)(a0w & 0xFFFFu), pts1 = (int)(a1w & 0xFFFFu);
+                const bool c0 = pts0 > 0, c1 = pts1 > 0;                           // ctr >= 1 (control >= 1)
+                if (c0 != c1) {                                                    // exactly one controller, :729
+                    const int pid = c0 ? 0 : 1;
+                    if (abs(cs) < cp || pid != cb) {                               // :731-732
+                        const int pxer = pid == 0 ? 1 : -1;
+                        const int old_sign = cs < 0;
+                        cs += (pid == 0 ? pts0 : pts1) * pxer;                     // :748 (turn > 0 here)
+                        const bool neutralize = old_sign != (cs < 0);              // :747-750
+                        if (abs(cs) >= cp) { cs = cp * pxer; cb = pid; }           // :763-765
+                        if (cb != -1 && neutralize) cb = -1;                       // :766-767
+                        L.NW[n][E] = (uint32_t)(cs + 512) | ((uint32_t)(cb + 1) << 10);
                     }
                 }
-                L.G[k][lane] = w;
+            }
+            if (ts != -1 && cb != -1 && cb != ts) {                                // :299-304
+                base_cap = 1;
+                if (cb == 0) part0 += 1000; else part1 += 1000;
+            }
+            if (cs != 0) {                                                         // :305-310
+                const int pts = abs(cs) == cp ? 2 * cp : abs(cs);
+                if (cs > 0) part0 += pts; else part1 += pts;
             }
         }
     }
-
-    // ---------------- per-node aggregates of the (post-movement) state
-#pragma unroll
-    for (int i = 0; i < 24; ++i) L.u.A[i][lane] = 0;
-    int unit_score[2] = {0, 0}, units_alive[2] = {0, 0};
-    uint32_t gw[24];
-#pragma unroll
-    for (int k = 0; k < 24; ++k) {
-        const uint32_t w = L.G[k][lane];
-        gw[k] = w;
-        const int cnt = __popc(w & G_MASK_M);
-        if (cnt) {
-            const int type = T->group_type[k / 12][k % 12];
-            const bool elig = ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;                      // :720
-            const uint32_t add = (elig ? (uint32_t)(cnt * T->unit_control[type]) : 0u) | ((uint32_t)cnt << 16);
-            L.u.A[(k / 12) * 12 + (w & G_LOC_M)][lane] += add;
-            unit_score[k / 12] += cnt * T->unit_cost[type];                                     // :315-317
-            units_alive[k / 12] += cnt;
-        }
-    }
-
-    // ---------------- capture (server.py:708-767), scores and status (server.py:281-348)
-    int score[2] = {unit_score[0], unit_score[1]};
-    bool base_captured = false;
-    int cs_arr[12];
-    uint32_t units_w[12][2];
-#pragma unroll
-    for (int n = 1; n <= NN; ++n) {
-        const uint32_t a0 = L.u.A[n][lane], a1 = L.u.A[12 + n][lane];
-        uint32_t nword = L.NW[n][lane];
-        int cs = (int)(nword & 0x3FFu) - 512;
-        int cb = (int)((nword >> 10) & 3u) - 1;
-        const int cp = T->control_points[n];
-        if (play) {
-            const int pts0 = (int)(a0 & 0xFFFFu), pts1 = (int)(a1 & 0xFFFFu);
-            const bool c0 = pts0 > 0, c1 = pts1 > 0;                               // ctr >= 1 (control >= 1)
-            if (c0 != c1) {                                                        // exactly one controller, :729
-                const int pid = c0 ? 0 : 1;
-                if (abs(cs) < cp || pid != cb) {                                   // :731-732
-                    const int pxer = pid == 0 ? 1 : -1;
-                    const int old_sign = cs < 0;
-                    cs += (pid == 0 ? pts0 : pts1) * pxer;                         // :748 (turn > 0 here)
-                    const bool neutralize = old_sign != (cs < 0);                  // :747-750
-                    if (abs(cs) >= cp) { cs = cp * pxer; cb = pid; }               // :763-765
-                    if (cb != -1 && neutralize) cb = -1;                           // :766-767
-                    nword = (uint32_t)(cs + 512) | ((uint32_t)(cb + 1) << 10);
-                    L.NW[n][lane] = nword;
-                }
-            }
-        }
-        const int ts = T->team_start[n];
-        if (ts != -1 && cb != -1 && cb != ts) {                                    // :299-304
-            base_captured = true;
-            score[cb == 0 ? 0 : 1] += 1000;
-        }
-        if (cs != 0) {                                                             // :305-310
-            const int pts = abs(cs) == cp ? 2 * cp : abs(cs);
-            if (cs > 0) score[0] += pts; else score[1] += pts;
-        }
-        cs_arr[n] = cs;
-        units_w[n][0] = a0 >> 16;
-        units_w[n][1] = a1 >> 16;
-    }
+    // combine the pair: scores (server.py:291-317) and status (:321-328) are then known to both lanes
+    const int opp_unit_score = xchg1(my_unit_score), opp_alive = xchg1(my_alive);
+    part0 += xchg1(part0);
+    part1 += xchg1(part1);
+    base_cap |= xchg1(base_cap);
+    int score[2];
+    score[0] = part0 + (P ? opp_unit_score : my_unit_score);
+    score[1] = part1 + (P ? my_unit_score : opp_unit_score);
     if (play) {
         if (turn >= max_turns) status = EVG_TIME_EXPIRED;                          // :321
-        else if (units_alive[0] + units_alive[1] == 0) status = EVG_ANNIHILATION;  // :324
-        else if (base_captured) status = EVG_BASE_CAPTURE;                         // :327
+        else if (my_alive + opp_alive == 0) status = EVG_ANNIHILATION;             // :324
+        else if (base_cap) status = EVG_BASE_CAPTURE;                              // :327
     }
+    STAMP(8);
 
     // ---------------- reward / done / winner (everglades_env.py:37-61, evaluate.py:155-160)
     float rew0, rew1;
@@ -440,7 +484,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         rew0 = (float)((double)score[0] / (double)EVG_MAX_SCORE);
         rew1 = (float)((double)score[1] / (double)EVG_MAX_SCORE);
     }
-    if (valid && !observe_only) {
+    if (valid && !observe_only && P == 0) {
         reinterpret_cast<float2*>(io.reward)[e] = make_float2(rew0, rew1);
         io.done[e] = done ? 1 : 0;
         if (io.winner) io.winner[e] = (int8_t)winner;
@@ -448,21 +492,19 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         if (io.status) io.status[e] = (uint8_t)status;
     }
 
-    // ---------------- episode bookkeeping + auto-reset
+    // ---------------- episode bookkeeping + auto-reset (each lane keeps its own player's return)
     bool do_reset = false;
     if (play) {
-        float r0 = S.ep_ret[e] + rew0, r1 = S.ep_ret[N + e] + rew1;
+        float r = S.ep_ret[(size_t)P * N + e] + (P ? rew1 : rew0);
         if (done) {
-            reinterpret_cast<float2*>(S.fin_ret)[e] = make_float2(r0, r1);
-            S.fin_len[e] = turn;
-            S.fin_win[e] = (int8_t)winner;
-            if (S.auto_reset) { do_reset = true; r0 = r1 = 0.f; }
+            S.fin_ret[(size_t)e * 2 + P] = r;
+            if (P == 0) { S.fin_len[e] = turn; S.fin_win[e] = (int8_t)winner; }
+            if (S.auto_reset) { do_reset = true; r = 0.f; }
         }
-        S.ep_ret[e] = r0;
-        S.ep_ret[N + e] = r1;
+        S.ep_ret[(size_t)P * N + e] = r;
     }
     {
-        const bool fin = play && done;
+        const bool fin = play && done && P == 0;
         const uint64_t mf = __ballot(fin);
         if (mf) {
             const uint64_t m0 = __ballot(fin && winner == EVG_WINNER_P0), m1 = __ballot(fin && winner == EVG_WINNER_P1);
@@ -475,78 +517,104 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
             }
         }
     }
-
-    // ---------------- observation record (board_state :382-455, player_state :457-501)
-    __syncthreads();        // all lanes have read their A columns before anyone overwrites the union with records
-    uint32_t* rec = &L.u.R[lane * REC_WORDS];
     if (do_reset) {
-        // new episode: state of game_init (server.py:133-209), observation of everglades_env.py:75-116
+        // new episode: state of game_init (server.py:133-209)
         turn = 0; status = 0; episode += 1u;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) st[j] = 0;
+        for (int j = 0; j < 3; ++j) st[j] = 0;
 #pragma unroll
-        for (int k = 0; k < 24; ++k) gw[k] = T->init_grp[k];
+        for (int k = 0; k < 12; ++k) gw[k] = P ? T->init_grp[12 + k] : T->init_grp[k];
 #pragma unroll
-        for (int n = 1; n <= NN; ++n) L.NW[n][lane] = T->init_node[n];
-#pragma unroll
-        for (int wd = 0; wd < REC_WORDS; ++wd) rec[wd] = T->reset_rec[wd];
-    } else {
-        // fields: 0 turn | 1..11 controlState | 12..22 p1 units at node | 23..33 p0 units at node |
-        //         34 + 4*(p*12+k) + {0 location (own numbering), 1 avg health, 2 moving, 3 alive}
-        int f[34];
-        f[0] = turn;
-#pragma unroll
-        for (int n = 1; n <= NN; ++n) { f[n] = cs_arr[n]; f[11 + n] = (int)units_w[n][1]; f[22 + n] = (int)units_w[n][0]; }
-#pragma unroll
-        for (int j = 0; j < 17; ++j) rec[j] = ((uint32_t)f[2 * j] & 0xFFFFu) | ((uint32_t)f[2 * j + 1] << 16);
-#pragma unroll
-        for (int k = 0; k < 24; ++k) {
-            const uint32_t w = gw[k];
-            uint32_t loc = w & G_LOC_M;
-            if (k >= 12) loc = (uint32_t)((p1nib >> (4 * loc)) & 15u);             // :485-486
-            const uint32_t avg = (w & G_AVG_M) >> G_AVG_S;
-            const uint32_t moving = ((w & G_MODE_M) >> G_MODE_S) == MODE_MOVING ? 1u : 0u;
-            const uint32_t alive = __popc(w & G_MASK_M);
-            rec[17 + 2 * k] = loc | (avg << 16);
-            rec[17 + 2 * k + 1] = moving | (alive << 16);
+        for (int j = 0; j < 6; ++j) {
+            const int n = P ? 7 + j : 1 + j;
+            if (n <= NN) L.NW[n][E] = P ? T->init_node[(7 + j) % 12] : T->init_node[1 + j];
         }
     }
+    __syncthreads();        // node words final; everybody is done adding to A
+    STAMP(9);
+
+    // ---------------- observation of this lane's player (board_state :382-455, player_state :457-501,
+    // everglades_env.py:158-171), written as int16 straight into the wave's output image in LDS
+    int cs_s[12], ou_s[12];
+#pragma unroll
+    for (int i = 1; i <= NN; ++i) {
+        const int n = P ? (int)((p1nib >> (4 * i)) & 15u) : i;                    // slot i of player 1 shows node p1_node_map[i] (:437-439)
+        cs_s[i] = (int)(L.NW[n][E] & 0x3FFu) - 512;                               // control sign not mirrored
+        ou_s[i] = (int)(L.u.A[n][lane ^ 1] >> 16);                                // opposing units listed at the node, moving ones included
+    }
+    __syncthreads();        // A is dead from here on: the union becomes the output image
+    int16_t* orow = &L.u.O[lane * OBS];
+    if (do_reset) {
+#pragma unroll
+        for (int i = 0; i < OBS; ++i) orow[i] = P ? T->reset_obs[OBS + i] : T->reset_obs[i];
+    } else {
+        orow[0] = (int16_t)turn;
+#pragma unroll
+        for (int i = 1; i <= NN; ++i) {
+            const int res = P ? T->resource[(int)((p1nib >> (4 * i)) & 15u)] : T->resource[i];
+            int16_t* o = orow + 1 + 4 * (i - 1);
+            o[0] = (res & EVG_RES_DEFENSE) ? 1 : 0;                                // :442
+            o[1] = (res & EVG_RES_OBSERVE) ? 1 : 0;                                // :443
+            o[2] = (int16_t)cs_s[i];
+            o[3] = (int16_t)ou_s[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t w = gw[k];
+            const uint32_t loc = w & G_LOC_M;
+            int16_t* o = orow + 45 + 5 * k;
+            o[0] = (int16_t)(P ? (uint32_t)((p1nib >> (4 * loc)) & 15u) : loc);    // :485-486
+            o[1] = (int16_t)((typ_n >> (4 * k)) & 15u);
+            o[2] = (int16_t)((w & G_AVG_M) >> G_AVG_S);
+            o[3] = (int16_t)(((w & G_MODE_M) >> G_MODE_S) == MODE_MOVING ? 1 : 0);
+            o[4] = (int16_t)__popc(w & G_MASK_M);
+        }
+    }
+    STAMP(10);
 
     // ---------------- store state (coalesced)
     if (valid && !observe_only && (play || do_reset) && !(abl & 32u)) {
 #pragma unroll
-        for (int k = 0; k < 24; ++k) S.grp[(size_t)k * N + e] = gw[k];
+        for (int k = 0; k < 12; ++k) S.grp[(size_t)(P * 12 + k) * N + e] = gw[k];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) S.stamp[(size_t)j * N + e] = st[j];
+        for (int j = 0; j < 3; ++j) S.stamp[(size_t)(P * 3 + j) * N + e] = st[j];
 #pragma unroll
-        for (int n = 1; n <= NN; ++n) S.node[(size_t)(n - 1) * N + e] = (uint16_t)L.NW[n][lane];
-        S.env[e] = (uint32_t)turn | ((uint32_t)status << 8);
-        if (do_reset) S.episode[e] = episode;
+        for (int j = 0; j < 6; ++j) {
+            const int n = P ? 7 + j : 1 + j;
+            if (n <= NN) S.node[(size_t)(n - 1) * N + e] = (uint16_t)L.NW[n][E];
+        }
+        if (P == 0) {
+            S.env[e] = (uint32_t)turn | ((uint32_t)status << 8);
+            if (do_reset) S.episode[e] = episode;
+        }
     }
-    __syncthreads();        // records visible to the whole wave; combat's health stores drained
+    __syncthreads();        // output image complete; combat's health stores drained
+    STAMP(11);
 
-    // ---------------- observation write-out: 64 envs x 2 x 105 elements, 16 bytes per lane, coalesced
+    // ---------------- observation write-out: the wave's 32 x 210 values are contiguous in the output; every lane
+    // converts 16 bytes' worth per iteration (conflict-free LDS reads, fully coalesced 1 KiB stores per wave)
     if (io.obs && !(abl & 16u)) {
         constexpr int EP = 16 / (int)sizeof(OT);          // elements per 16-byte vector
-        constexpr int U = EP == 2 ? 1 : (EP == 4 ? 2 : 4); // envs per descriptor unit: U*210 % EP == 0
-        constexpr int VPU = U * 2 * OBS / EP;              // = 105 vectors per unit
-        const int nvec = (WG / U) * VPU;
-        const int limit = nvalid * 2 * OBS;
-        OT* out = reinterpret_cast<OT*>(io.obs) + (size_t)e0 * (2 * OBS);
+        constexpr int NVEC = WG * OBS / EP;
+        const int limit = nvalid * OBS2;
+        OT* out = reinterpret_cast<OT*>(io.obs) + (size_t)e0 * OBS2;
 #pragma unroll 4
-        for (int v = lane; v < nvec; v += WG) {
-            const int unit = v / VPU, r = v - unit * VPU;
-            int vals[EP];
-#pragma unroll
-            for (int j = 0; j < EP; ++j) {
-                const uint32_t d = L.desc[r * EP + j];
-                const int el = unit * U + (int)((d >> 8) & 3u);
-                const uint32_t fld = d & 0xFFu;
-                const uint32_t word = L.u.R[el * REC_WORDS + (fld >> 1)];
-                const int fv = (int)(int16_t)(word >> (16 * (fld & 1u)));
-                vals[j] = (d & 0x8000u) ? (int)(d & 0x7FFFu) : fv;
-            }
+        for (int v = lane; v < NVEC; v += WG) {
             const int elem0 = v * EP;
+            int vals[EP];
+            if constexpr (EP == 4) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(&L.u.O[elem0]);
+                vals[0] = (int)(int16_t)(raw.x & 0xFFFFu); vals[1] = (int)(int16_t)(raw.x >> 16);
+                vals[2] = (int)(int16_t)(raw.y & 0xFFFFu); vals[3] = (int)(int16_t)(raw.y >> 16);
+            } else if constexpr (EP == 2) {
+                const uint32_t raw = *reinterpret_cast<const uint32_t*>(&L.u.O[elem0]);
+                vals[0] = (int)(int16_t)(raw & 0xFFFFu); vals[1] = (int)(int16_t)(raw >> 16);
+            } else {
+                const uint4 raw = *reinterpret_cast<const uint4*>(&L.u.O[elem0]);
+                const uint32_t r4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vals[2 * j] = (int)(int16_t)(r4[j] & 0xFFFFu); vals[2 * j + 1] = (int)(int16_t)(r4[j] >> 16); }
+            }
             if (elem0 + EP <= limit) {
                 store_obs_vec<OT>(out + elem0, vals);
             } else {
@@ -556,15 +624,17 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
             }
         }
     }
+    STAMP(12);
 
     // ---------------- health of envs that start a new episode: 1600 B each, written by the whole wave
-    uint64_t rm = __ballot(do_reset);
+    uint64_t rm = __ballot(do_reset && P == 0);
     while (rm) {
         const int l = __ffsll((unsigned long long)rm) - 1;
         rm &= rm - 1;
-        double2* dst = reinterpret_cast<double2*>(S.health + (size_t)(e0 + l) * (2 * NU));
+        double2* dst = reinterpret_cast<double2*>(S.health + (size_t)(e0 + (l >> 1)) * (2 * NU));
         for (int i = lane; i < NU; i += WG) dst[i] = make_double2(100.0, 100.0);
     }
+    STAMP(13);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -643,7 +713,7 @@ __global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int
 // launchers
 // ---------------------------------------------------------------------------------------------
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
-    const dim3 grid((S.N + WG - 1) / WG), block(WG);
+    const dim3 grid((S.N + EPW - 1) / EPW), block(WG);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (obs_dtype) {
         case EVG_OBS_F32: hipLaunchKernelGGL(evg_step_kernel<float>, grid, block, 0, s, S, io); break;

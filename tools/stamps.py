@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a wave of the step kernel spend its cycles?  Needs `make -C .../csrc stamps`
+(libevg_stamps.so, s_memtime at phase boundaries).  Not part of the product path, not a benchmark."""
+import ctypes as C
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["EVG_LIB_PATH"] = os.path.join(ROOT, "everglades-ai-wargame_amd", "libevg_stamps.so")
+import numpy as np
+import torch
+import everglades_amd as evg
+
+NAMES = ["tables+state load", "orders", "combat0 snapshot", "combat1 worklist", "combatA draws", "combatB apply", "movement",
+         "aggregates+capture", "rewards+stats+reset", "obs build", "state store", "obs write-out", "reset fill"]
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True)
+env.reset()
+L = env.L
+L.evg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
+nb = (N + 31) // 32
+for upto in (20, 80, 140):
+    cur = int(env.get_state()["env"][0, 0])
+    env.rollout_random(upto - cur)
+    st = np.zeros((nb, 16), np.uint64)
+    assert L.evg_debug_read_stamps(env._h, st.ctypes.data_as(C.c_void_p)) == 0
+    d = np.diff(st[:, :14].astype(np.int64), axis=1)
+    d = np.where(d < 0, 0, d)      # stamps inside the skipped combat block keep older values
+    tot = (st[:, 13] - st[:, 0]).astype(np.int64)
+    span = int(st[:, 13].max() - st[:, 0].min())
+    print("turn %d: mean wave %.0f cycles (max %.0f), first-start to last-end %d cycles (memtime ticks, 100 MHz => x10 ns)" % (upto, tot.mean(), tot.max(), span))
+    for i, nm in enumerate(NAMES):
+        print("   %-20s mean %8.0f  max %8.0f  (%4.1f%%)" % (nm, d[:, i].mean(), d[:, i].max(), 100.0 * d[:, i].mean() / tot.mean()))
+env.close()
