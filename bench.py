@@ -25,6 +25,25 @@ ALGO_BYTES_PER_ENV_STEP = 4530
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def usable_cores():
+    """CPUs this job may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs but grants a 16-CPU share per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(seed, budget_s=12.0):
     """The CPU oracle (C port of the reference's turn loop, oracle/evg_oracle.c) timed on this box's host
     cores with OpenMP over envs: same workload (random vs random incl. action generation and observations,
@@ -34,7 +53,7 @@ def cpu_baseline(seed, budget_s=12.0):
     import numpy as np
     import oracle as om
     L = om.lib()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     L.evo_set_num_threads(cores)
     n = 8192
     o = om.Oracle(n, seed=seed, auto_reset=True)
@@ -96,40 +115,45 @@ def main():
     stats_dev = env.episode_stats_device()
     period = 150                                   # episode length of random vs random: gather at episode boundaries
 
-    def one_step():
-        env.step(env.random_actions())
-
     def barrier():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        one_step()
-    if world > 1:                                  # warm the collective too
-        evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total)
+    def run(nsteps, timed):
+        """nsteps turns through the native rollout driver (evg_rollout_random: per turn the random_actions kernel then
+        the step kernel, enqueued from C on torch's current stream), split at episode boundaries (every 150 turns for
+        random vs random) where the episode results are gathered.  Returns the summed step-kernel time in ms (HIP
+        events recorded on that stream around every step-kernel launch) and the last gather."""
+        nonlocal turn_counter
+        kernel_ms_sum, gathered = 0.0, None
+        left = nsteps
+        while left > 0:
+            chunk = min(left, period - turn_counter % period)
+            out = env.rollout_random(chunk, time_kernel=timed)
+            if timed:
+                kernel_ms_sum += out[-1] * chunk
+            turn_counter += chunk
+            left -= chunk
+            if turn_counter % period == 0:
+                gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total)
+        return kernel_ms_sum, gathered
+
+    turn_counter = 0
+    run(args.warmup, False)
 
     # ---- timed region: exactly K steps
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    gathered = None
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        a = env.random_actions()
-        ev0[i].record()                            # same stream the kernels are launched on (torch's current stream)
-        env.step(a)
-        ev1[i].record()
-        if (args.warmup + i + 1) % period == 0:
-            gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total)
+    kernel_ms_sum, gathered = run(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    step_kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    step_kernel_ms = kernel_ms_sum / args.steps
 
     if rank == 0:
         value = total * args.steps / dt

@@ -93,7 +93,8 @@ __device__ __forceinline__ void store_obs_vec<int16_t>(int16_t* dst, const int (
     *reinterpret_cast<uint4*>(dst) = o;
 }
 
-__device__ __forceinline__ int xchg1(int v) { return __shfl_xor(v, 1); }     // value of the other player's lane
+// value held by the other player's lane of the same env (lane ^ 1): one DPP quad_perm [1,0,3,2] move, no LDS round trip
+__device__ __forceinline__ int xchg1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 
 // ---------------------------------------------------------------------------------------------
 // fused env-step: lane = (env slot, player); 32 envs per wavefront
@@ -237,15 +238,15 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
 
         // Stage 1: wave-wide work list (one item per fighting group) and damage-pool layout, by prefix scan
         const int nfight = __popc(fmask);
-        int incl_i = nfight, incl_d = ndw;
+        int incl = (ndw << 16) | nfight;                  // both counts in one scan: totals stay below 2^16 (<= 768 items, <= 2112 words)
 #pragma unroll
         for (int d = 1; d < WG; d <<= 1) {
-            const int ti = __shfl_up(incl_i, d), td = __shfl_up(incl_d, d);
-            if (lane >= d) { incl_i += ti; incl_d += td; }
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
         }
-        const int excl_i = incl_i - nfight, excl_d = incl_d - ndw;
-        const int tot_i = __shfl(incl_i, WG - 1), tot_d = __shfl(incl_d, WG - 1);
-        const int mid_i = __shfl(excl_i, WG / 2), mid_d = __shfl(excl_d, WG / 2);
+        const int excl = incl - ((ndw << 16) | nfight);
+        const int tot = __shfl(incl, WG - 1), mid = __shfl(excl, WG / 2);
+        const int excl_i = excl & 0xFFFF, excl_d = excl >> 16, tot_i = tot & 0xFFFF, tot_d = tot >> 16, mid_i = mid & 0xFFFF, mid_d = mid >> 16;
         // the pool holds every fight of the wave in the common case; otherwise two passes of 16 envs each
         const int npass = tot_d <= DP_CAP ? 1 : 2;
         const uint32_t dmg_nib = T->damage_nib, armor_byte = T->armor_byte;
@@ -276,6 +277,25 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
             for (int i = lane; i < ndwords; i += WG) L.u.c.DP[i] = 0;
             __syncthreads();
             STAMP(4);
+
+            // health row of this lane's first item: issued now, consumed in phase B, so that the HBM latency hides
+            // behind the draws (a fighting group is very likely to be hit; 64-96 B per group)
+            double hpre[12];
+            {
+                const uint32_t item0 = L.u.c.W[lane < nitems ? lane : 0];
+                const int SL0 = (int)(item0 & 63u), gid0 = (int)(item0 >> 6);
+                const double2* r2 = reinterpret_cast<const double2*>(S.health + (size_t)(e0 + (SL0 >> 1)) * (2 * NU) + (SL0 & 1) * NU + gid0 * 8);
+                if (lane < nitems) {
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) { const double2 v = r2[sl]; hpre[2 * sl] = v.x; hpre[2 * sl + 1] = v.y; }
+                    if (gid0 == 11) {
+#pragma unroll
+                        for (int sl = 4; sl < 6; ++sl) { const double2 v = r2[sl]; hpre[2 * sl] = v.x; hpre[2 * sl + 1] = v.y; }
+                    } else {
+                        hpre[8] = hpre[9] = hpre[10] = hpre[11] = 0.0;
+                    }
+                }
+            }
 
             // Phase A (:549-566): one lane per fighting group; each of its alive units draws one target among the
             // opposing side's alive fighting units at the node; damage accumulates in the pool (LDS atomics,
@@ -331,14 +351,19 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
                 if (any) {
                     double* row = S.health + (size_t)(e0 + (SL >> 1)) * (2 * NU) + side * NU + gid * 8;
                     double h[12];
-                    const double2* r2 = reinterpret_cast<const double2*>(row);
+                    if (it < WG) {                                  // first round: prefetched before the draws
 #pragma unroll
-                    for (int sl = 0; sl < 4; ++sl) { const double2 v = r2[sl]; h[2 * sl] = v.x; h[2 * sl + 1] = v.y; }
-                    if (gid == 11) {
-#pragma unroll
-                        for (int sl = 4; sl < 6; ++sl) { const double2 v = r2[sl]; h[2 * sl] = v.x; h[2 * sl + 1] = v.y; }
+                        for (int sl = 0; sl < 12; ++sl) h[sl] = hpre[sl];
                     } else {
-                        h[8] = h[9] = h[10] = h[11] = 0.0;
+                        const double2* r2 = reinterpret_cast<const double2*>(row);
+#pragma unroll
+                        for (int sl = 0; sl < 4; ++sl) { const double2 v = r2[sl]; h[2 * sl] = v.x; h[2 * sl + 1] = v.y; }
+                        if (gid == 11) {
+#pragma unroll
+                            for (int sl = 4; sl < 6; ++sl) { const double2 v = r2[sl]; h[2 * sl] = v.x; h[2 * sl + 1] = v.y; }
+                        } else {
+                            h[8] = h[9] = h[10] = h[11] = 0.0;
+                        }
                     }
                     const uint64_t tn_s = side ? T->type_nib[1] : T->type_nib[0];
                     const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
