@@ -164,8 +164,8 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": "%d concurrent DemoMap games per GPU, random_actions vs random_actions generated on device, "
-                                   "auto-reset, obs %s [N,2,105]" % (n_local, args.obs_dtype),
+            "config": {"workload": "%d concurrent DemoMap games per GPU, random_actions vs random_actions drawn on device (fused into the "
+                                   "step kernel, orders written to an [N,2,7,2] tensor), auto-reset, obs %s [N,2,105]" % (n_local, args.obs_dtype),
                        "envs_per_gpu": n_local, "total_envs": total, "parallelism": "env-sharded x%d" % world,
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],

@@ -73,7 +73,7 @@ def load():
     L.evg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.evg_observe.argtypes = [vp, vp, vp]
     L.evg_random_actions.argtypes = [vp, vp, vp]
-    L.evg_rollout_random.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]
+    L.evg_rollout_random.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]
     L.evg_get_state.argtypes = [vp, vp, vp, vp, vp]
     L.evg_set_state.argtypes = [vp, vp, vp, vp, vp]
     L.evg_episode_stats.argtypes = [vp, vp, vp, vp, vp]

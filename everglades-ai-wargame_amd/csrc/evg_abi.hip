@@ -287,7 +287,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, h->stamps, h->ablate};
+    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, nullptr, h->stamps, h->ablate};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -296,7 +296,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
 int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0};
+    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, 0};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -310,37 +310,40 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
     return EVG_OK;
 }
 
-int evg_rollout_random(evg_handle* h, int steps, int32_t* actions_buf, void* obs_out, float* reward_out, uint8_t* done_out,
+int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf, void* obs_out, float* reward_out, uint8_t* done_out,
                        int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (steps < 1 || !actions_buf || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, actions_buf, reward_out, done_out required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (step_kernel_ms) {
-        while (h->events.size() < (size_t)2 * steps) {
-            hipEvent_t ev;
-            HIP_TRY(hipEventCreate(&ev));
-            h->events.push_back(ev);
-        }
+    // Event pairs make the queue wait for each bracketed kernel to retire, so only every 8th launch is bracketed:
+    // the sample prices the kernel, the unbracketed launches keep the stream back-to-back.
+    constexpr int kSampleEvery = 8;
+    const int nsamples = step_kernel_ms ? (steps + kSampleEvery - 1) / kSampleEvery : 0;
+    while (h->events.size() < (size_t)2 * nsamples) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        h->events.push_back(ev);
     }
-    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, h->stamps, h->ablate};
+    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? 1 : 0, actions_buf, h->stamps, h->ablate};
     for (int i = 0; i < steps; ++i) {
-        int rc = launch_random_actions(h->S, actions_buf, stream);
+        int rc = fused ? 0 : launch_random_actions(h->S, actions_buf, stream);
         if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
-        if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * i], s));
+        const bool sample = step_kernel_ms && i % kSampleEvery == 0;
+        if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery)], s));
         rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
         if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
-        if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * i + 1], s));
+        if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery) + 1], s));
     }
     if (step_kernel_ms) {
         HIP_TRY(hipStreamSynchronize(s));
         double tot = 0.0;
-        for (int i = 0; i < steps; ++i) {
+        for (int i = 0; i < nsamples; ++i) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]));
             tot += ms;
         }
-        *step_kernel_ms = (float)(tot / steps);
+        *step_kernel_ms = (float)(tot / nsamples);
     }
     return EVG_OK;
 }

@@ -94,6 +94,34 @@ __device__ __forceinline__ void store_obs_vec<int16_t>(int16_t* dst, const int (
 }
 
 // value held by the other player's lane of the same env (lane ^ 1): one DPP quad_perm [1,0,3,2] move, no LDS round trip
+// random_actions stand-in for one (env, player): 7 distinct groups of 12 and 7 distinct nodes of 1..11
+// (agents/State_Machine/random_actions.py:38-46), partial Fisher-Yates on nibble-packed permutations.
+// Same contract as oracle/rng_spec.py random_action_rows.
+__device__ __forceinline__ void gen_random_rows(const DevState& S, uint32_t env_id, uint32_t episode, int turn, int p, int2 (&rows)[NA]) {
+    uint32_t w[16];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_ACTION, (uint32_t)b, turn, 0, p, 0);
+        w[4 * b] = x.x; w[4 * b + 1] = x.y; w[4 * b + 2] = x.z; w[4 * b + 3] = x.w;
+    }
+    uint64_t gp = 0xBA9876543210ull;      // nibble i = i
+    uint64_t np_ = 0xBA987654321ull;      // nibble i = i + 1
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int j = i + (int)__umulhi(w[i], (uint32_t)(12 - i));
+        const uint64_t x = ((gp >> (4 * i)) ^ (gp >> (4 * j))) & 15ull;
+        gp ^= (x << (4 * i)) ^ (x << (4 * j));
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int j = i + (int)__umulhi(w[8 + i], (uint32_t)(11 - i));
+        const uint64_t x = ((np_ >> (4 * i)) ^ (np_ >> (4 * j))) & 15ull;
+        np_ ^= (x << (4 * i)) ^ (x << (4 * j));
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rows[i] = make_int2((int)((gp >> (4 * i)) & 15ull), (int)((np_ >> (4 * i)) & 15ull));
+}
+
 __device__ __forceinline__ int xchg1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 
 // ---------------------------------------------------------------------------------------------
@@ -139,6 +167,21 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         const int n = P ? 7 + j : 1 + j;
         if (n <= NN) L.NW[n][E] = S.node[(size_t)(n - 1) * N + e];
     }
+    // this player's 7 order rows: read from the caller's tensor (issued now, used after the barrier), or -- in the
+    // fused random-vs-random rollout -- drawn here by the same generator as evg_random_actions and written out
+    int2 act[NA];
+    if (io.gen_actions) {
+        gen_random_rows(S, S.env_id_base + (uint32_t)e, episode, turn, P, act);
+        if (valid && io.actions_out) {
+            int2* ao = reinterpret_cast<int2*>(io.actions_out) + ((size_t)e * 2 + P) * NA;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ao[i] = act[i];
+        }
+    } else {
+        const int2* ap = reinterpret_cast<const int2*>(io.actions) + ((size_t)e * 2 + P) * NA;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) act[i] = io.actions ? ap[i] : make_int2(0, 0);
+    }
     __syncthreads();
     STAMP(1);
 
@@ -150,27 +193,35 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     if (play) {
         turn += 1;                                                               // server.py:214
         // ---------------- orders of this lane's player (server.py:218-271)
+        // Accepting an order changes neither the group's location nor whether it is `moving`, so tests 2 and 3
+        // of every row can be taken from the pre-order words; rows interact only through test 1 (a group already
+        // commanded this turn).  That makes the 7 LDS lookups independent instead of a 7-deep dependent chain.
         if (!(abl & 1u)) {
-            const int2* ap = reinterpret_cast<const int2*>(io.actions) + ((size_t)e * 2 + P) * NA;
-            int2 a[NA];
+            int gidv[NA], nidv[NA];
+            uint32_t wv[NA], dv[NA];
+            bool okv[NA];
 #pragma unroll
-            for (int i = 0; i < NA; ++i) a[i] = ap[i];
+            for (int i = 0; i < NA; ++i) {
+                int gid = act[i].x, nid = act[i].y;
+                okv[i] = (uint32_t)gid < 12u && (uint32_t)nid < 12u;            // build-defined domain
+                gid = okv[i] ? gid : 0;
+                nid = okv[i] ? nid : 0;
+                nidv[i] = P ? (int)((p1nib >> (4 * nid)) & 15u) : nid;           // :233-234
+                gidv[i] = gid;
+                wv[i] = L.G[gid][lane];
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                dv[i] = (uint32_t)((L.adj[wv[i] & G_LOC_M] >> (4 * nidv[i])) & 15u);   // test3 + distance, :245-250
             uint32_t used = 0;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                int gid = a[i].x, nid = a[i].y;
-                const bool ok = (uint32_t)gid < 12u && (uint32_t)nid < 12u;     // build-defined domain
-                gid = ok ? gid : 0;
-                nid = ok ? nid : 0;
-                nid = P ? (int)((p1nib >> (4 * nid)) & 15u) : nid;               // :233-234
-                const uint32_t w = L.G[gid][lane];
-                const int loc = (int)(w & G_LOC_M);
-                const uint32_t d = (uint32_t)((L.adj[loc] >> (4 * nid)) & 15u);  // test3 + distance, :245-250
-                const bool accept = ok && !((used >> gid) & 1u) && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING && d != 0;
-                used |= (accept ? 1u : 0u) << gid;
-                const uint32_t nw_ = (w & ~(G_DEST_M | G_DIST_M | G_MODE_M)) | ((uint32_t)nid << G_DEST_S) | (d << G_DIST_S) |
-                                     (MODE_READY << G_MODE_S);                   // :267-270
-                L.G[gid][lane] = accept ? nw_ : w;
+                const uint32_t w = wv[i];
+                const bool accept = okv[i] && !((used >> gidv[i]) & 1u) && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING && dv[i] != 0;
+                used |= (accept ? 1u : 0u) << gidv[i];
+                if (accept)                                                      // :267-270
+                    L.G[gidv[i]][lane] = (w & ~(G_DEST_M | G_DIST_M | G_MODE_M)) | ((uint32_t)nidv[i] << G_DEST_S) | (dv[i] << G_DIST_S) |
+                                         (MODE_READY << G_MODE_S);
             }
         }
     }
@@ -337,16 +388,14 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
                 const int node = (int)((sp >> 12) & 15u);
                 const uint32_t mask = sp & 0xFFFu;
                 const uint32_t doff = L.u.c.FS[node][SL] & 0xFFFFu;
-                int idx = (int)((sp >> 16) & 0xFFu);
-                uint32_t dm[3] = {0, 0, 0}, any = 0;
+                const uint32_t base = (sp >> 16) & 0xFFu;
+                uint32_t dmv[12], any = 0;
 #pragma unroll
-                for (int sl = 0; sl < 12; ++sl) {
-                    if ((mask >> sl) & 1u) {
-                        const uint32_t d = (L.u.c.DP[doff + (idx >> 2)] >> (8 * (idx & 3))) & 0xFFu;
-                        ++idx;
-                        dm[sl >> 2] |= d << (8 * (sl & 3));
-                        any |= d;
-                    }
+                for (int sl = 0; sl < 12; ++sl) {            // rank of slot sl among the alive slots: no dependent chain, no branches
+                    const uint32_t idx = base + (uint32_t)__popc(mask & ((1u << sl) - 1u));
+                    const uint32_t wd = L.u.c.DP[min(doff + (idx >> 2), (uint32_t)(DP_CAP - 1))];
+                    dmv[sl] = ((mask >> sl) & 1u) ? ((wd >> (8 * (idx & 3u))) & 0xFFu) : 0u;
+                    any |= dmv[sl];
                 }
                 if (any) {
                     double* row = S.health + (size_t)(e0 + (SL >> 1)) * (2 * NU) + side * NU + gid * 8;
@@ -372,14 +421,12 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
                     const double denom = armor + (ctrl_by == side ? L.defense[node] : 0.0);          // :592-597 (fort bonus dead)
                     uint32_t newmask = mask;
 #pragma unroll
-                    for (int sl = 0; sl < 12; ++sl) {
-                        const uint32_t d = (dm[sl >> 2] >> (8 * (sl & 3))) & 0xFFu;
-                        if (d) {
-                            const double loss = (10.0 * (double)d) / denom;                           // :601
-                            double hv = h[sl] - loss;                                                 // :609
-                            if (hv <= 0.0) { hv = 0.0; newmask &= ~(1u << sl); }                      // :615-618
-                            h[sl] = hv;
-                        }
+                    for (int sl = 0; sl < 12; ++sl) {            // unconditional: an untouched unit loses exactly 0.0
+                        const double loss = (10.0 * (double)dmv[sl]) / denom;                         // :601
+                        double hv = h[sl] - loss;                                                     // :609
+                        const bool dead = hv <= 0.0;                                                  // :615-618
+                        h[sl] = dead ? 0.0 : hv;
+                        newmask &= dead ? ~(1u << sl) : ~0u;
                     }
                     double2* w2 = reinterpret_cast<double2*>(row);
 #pragma unroll
@@ -437,7 +484,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         const bool elig = ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;                          // :720
         const uint32_t ctl = (uint32_t)((ctl_n >> (4 * k)) & 15u);
         const uint32_t add = (elig ? (uint32_t)cnt * ctl : 0u) | ((uint32_t)cnt << 16);
-        if (cnt) atomicAdd(&L.u.A[w & G_LOC_M][lane], add);                                     // ds_add_u32
+        atomicAdd(&L.u.A[w & G_LOC_M][lane], add);                                              // ds_add_u32 (adds 0 for a destroyed group)
         my_unit_score += cnt * (int)((cst_n >> (4 * k)) & 15u);                                 // :315-317
         my_alive += cnt;
     }
@@ -446,40 +493,43 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     // ---------------- capture (server.py:708-767) and node scores (:297-310): the pair splits the nodes
     int part0 = 0, part1 = 0;          // score contributions of this lane's nodes to player 0 / player 1
     int base_cap = 0;
+    {
+        uint32_t a0v[6], a1v[6], nwv[6];
+        int cpv[6], tsv[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int n = P ? 7 + j : 1 + j;
-        if (n <= NN) {
-            const uint32_t a0w = L.u.A[n][lane & ~1], a1w = L.u.A[n][lane | 1];
-            uint32_t nword = L.NW[n][E];
-            int cs = (int)(nword & 0x3FFu) - 512;
-            int cb = (int)((nword >> 10) & 3u) - 1;
-            const int cp = P ? T->control_points[(7 + j) % 12] : T->control_points[1 + j];
-            const int ts = P ? T->team_start[(7 + j) % 12] : T->team_start[1 + j];
-            if (play) {
-                const int pts0 = (int)(a0w & 0xFFFFu), pts1 = (int)(a1w & 0xFFFFu);
-                const bool c0 = pts0 > 0, c1 = pts1 > 0;                           // ctr >= 1 (control >= 1)
-                if (c0 != c1) {                                                    // exactly one controller, :729
-                    const int pid = c0 ? 0 : 1;
-                    if (abs(cs) < cp || pid != cb) {                               // :731-732
-                        const int pxer = pid == 0 ? 1 : -1;
-                        const int old_sign = cs < 0;
-                        cs += (pid == 0 ? pts0 : pts1) * pxer;                     // :748 (turn > 0 here)
-                        const bool neutralize = old_sign != (cs < 0);              // :747-750
-                        if (abs(cs) >= cp) { cs = cp * pxer; cb = pid; }           // :763-765
-                        if (cb != -1 && neutralize) cb = -1;                       // :766-767
-                        L.NW[n][E] = (uint32_t)(cs + 512) | ((uint32_t)(cb + 1) << 10);
-                    }
-                }
-            }
-            if (ts != -1 && cb != -1 && cb != ts) {                                // :299-304
-                base_cap = 1;
-                if (cb == 0) part0 += 1000; else part1 += 1000;
-            }
-            if (cs != 0) {                                                         // :305-310
-                const int pts = abs(cs) == cp ? 2 * cp : abs(cs);
-                if (cs > 0) part0 += pts; else part1 += pts;
-            }
+        for (int j = 0; j < 6; ++j) {                  // all LDS / table reads first, then pure ALU
+            const int n = (P ? 7 + j : 1 + j) % 12;    // j = 5 of player 1 is the unused slot 0
+            a0v[j] = L.u.A[n][lane & ~1];
+            a1v[j] = L.u.A[n][lane | 1];
+            nwv[j] = L.NW[n][E];
+            cpv[j] = P ? T->control_points[(7 + j) % 12] : T->control_points[1 + j];
+            tsv[j] = P ? T->team_start[(7 + j) % 12] : T->team_start[1 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int n = P ? 7 + j : 1 + j;
+            const bool real = n <= NN;
+            int cs = (int)(nwv[j] & 0x3FFu) - 512;
+            int cb = (int)((nwv[j] >> 10) & 3u) - 1;
+            const int cp = cpv[j], ts = tsv[j];
+            const int pts0 = (int)(a0v[j] & 0xFFFFu), pts1 = (int)(a1v[j] & 0xFFFFu);
+            const bool c0 = pts0 > 0, c1 = pts1 > 0;                               // ctr >= 1 (control >= 1)
+            const int pid = c0 ? 0 : 1;
+            const bool capture = real && play && (c0 != c1) && (abs(cs) < cp || pid != cb);   // :729-732
+            const int pxer = pid == 0 ? 1 : -1;
+            const int cs2 = cs + (pid == 0 ? pts0 : pts1) * pxer;                  // :748 (turn > 0 here)
+            const bool neutralize = (cs < 0) != (cs2 < 0);                         // :747-750
+            const bool full = abs(cs2) >= cp;                                      // :763-765
+            int cb2 = full ? pid : cb;
+            cb2 = (cb2 != -1 && neutralize) ? -1 : cb2;                            // :766-767
+            cs = capture ? (full ? cp * pxer : cs2) : cs;
+            cb = capture ? cb2 : cb;
+            if (capture) L.NW[n % 12][E] = (uint32_t)(cs + 512) | ((uint32_t)(cb + 1) << 10);
+            const bool bcap = real && ts != -1 && cb != -1 && cb != ts;            // :299-304
+            base_cap |= bcap ? 1 : 0;
+            const int pts = real ? (abs(cs) == cp ? 2 * cp : abs(cs)) : 0;         // :305-310
+            part0 += (bcap && cb == 0 ? 1000 : 0) + (cs > 0 ? pts : 0);
+            part1 += (bcap && cb == 1 ? 1000 : 0) + (cs < 0 ? pts : 0);
         }
     }
     // combine the pair: scores (server.py:291-317) and status (:321-328) are then known to both lanes
@@ -709,29 +759,11 @@ __global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int
     const int turn = (int)(S.env[e] & 0xFFu);
     const uint32_t episode = S.episode[e];
     const uint32_t env_id = S.env_id_base + (uint32_t)e;
-    uint32_t w[16];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_ACTION, (uint32_t)b, turn, 0, p, 0);
-        w[4 * b] = x.x; w[4 * b + 1] = x.y; w[4 * b + 2] = x.z; w[4 * b + 3] = x.w;
-    }
-    uint64_t gp = 0xBA9876543210ull;      // nibble i = i
-    uint64_t np_ = 0xBA987654321ull;      // nibble i = i + 1
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int j = i + (int)__umulhi(w[i], (uint32_t)(12 - i));
-        const uint64_t x = ((gp >> (4 * i)) ^ (gp >> (4 * j))) & 15ull;
-        gp ^= (x << (4 * i)) ^ (x << (4 * j));
-    }
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int j = i + (int)__umulhi(w[8 + i], (uint32_t)(11 - i));
-        const uint64_t x = ((np_ >> (4 * i)) ^ (np_ >> (4 * j))) & 15ull;
-        np_ ^= (x << (4 * i)) ^ (x << (4 * j));
-    }
+    int2 rows[NA];
+    gen_random_rows(S, env_id, episode, turn, p, rows);
     int2* out = reinterpret_cast<int2*>(actions) + (size_t)idx * NA;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) out[i] = make_int2((int)((gp >> (4 * i)) & 15ull), (int)((np_ >> (4 * i)) & 15ull));
+    for (int i = 0; i < NA; ++i) out[i] = rows[i];
 }
 
 // ---------------------------------------------------------------------------------------------

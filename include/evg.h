@@ -145,10 +145,12 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream);
 /* Rollout driver for random-vs-random play (the reference's demo/random_demo.py:90-113 loop with both
  * agents = random_actions): enqueues `steps` x (evg_random_actions into actions_buf, then evg_step) on
  * `stream` from native code, so that launch cost, not the Python interpreter, bounds small batches.
+ * fused != 0: the step kernel draws the orders itself (same generator, same values) and stores them in
+ * actions_buf, which saves the second launch and the round trip of the action tensor through HBM.
  * Outputs as in evg_step (they hold the LAST step when the call returns).  If step_kernel_ms (host
- * pointer) is not NULL the step kernel of every iteration is bracketed by hipEvents on `stream`, the
- * call synchronises the stream and stores the average step-kernel duration in milliseconds. */
-int evg_rollout_random(evg_handle* h, int steps, int32_t* actions_buf, void* obs_out, float* reward_out,
+ * pointer) is not NULL the step kernel of every 8th iteration is bracketed by hipEvents on `stream`, the
+ * call synchronises the stream and stores the average of those step-kernel durations in milliseconds. */
+int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf, void* obs_out, float* reward_out,
                        uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
                        float* step_kernel_ms, void* stream);
 

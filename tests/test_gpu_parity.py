@@ -215,3 +215,29 @@ def test_full_size_properties(evg, oracle_mod):
     assert np.array_equal(st["winner"][lo:lo + n], ost["winner"]) and np.array_equal(st["length"][lo:lo + n], ost["length"])
     assert np.array_equal(s["health"][lo:lo + n], ora.get_state()["health"])
     env.close()
+
+
+def test_native_rollout_fused_equals_stepwise(evg, oracle_mod):
+    """evg_rollout_random: fused (orders drawn inside the step kernel) == unfused (generator kernel + step kernel)
+    == the oracle stepped with its own generator; the action buffer holds the last turn's orders."""
+    N, seed, steps = 300, 77, 170
+    a = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    b = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    a.reset(); b.reset(); ora.reset()
+    oa = a.rollout_random(steps, fused=True)
+    ob = b.rollout_random(steps, fused=False)
+    for t in range(steps):
+        last_actions = ora.random_actions()
+        o_obs, o_rew, o_done, o_info = ora.step(last_actions)
+    for x, y in zip(oa[:3], ob[:3]):
+        assert np.array_equal(_np(x), _np(y))
+    assert np.array_equal(_np(oa[0]).astype(np.float64), o_obs) and np.array_equal(_np(oa[3]["scores"]), o_info["scores"])
+    assert np.array_equal(_np(a._actions), last_actions) and np.array_equal(_np(b._actions), last_actions)
+    check_state(a, ora.get_state(), "fused")
+    check_state(b, ora.get_state(), "unfused")
+    sa, so = a.episode_stats(), ora.episode_stats()
+    assert np.array_equal(sa["totals"], so["totals"]) and np.array_equal(sa["winner"], so["winner"])
+    ms = a.rollout_random(10, time_kernel=True)[-1]
+    assert ms > 0
+    a.close(); b.close()
