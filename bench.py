@@ -44,6 +44,23 @@ def usable_cores():
     return n
 
 
+def pmc_traffic(n_local):
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md, calibrated in the same passes).
+    Counters cannot be read live from inside this process, so the newest committed figure for this config is
+    reported; None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            if int(d.get("envs", -1)) == n_local:
+                return float(d["corrected_bytes_per_launch"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def cpu_baseline(seed, budget_s=12.0):
     """The CPU oracle (C port of the reference's turn loop, oracle/evg_oracle.c) timed on this box's host
     cores with OpenMP over envs: same workload (random vs random incl. action generation and observations,
@@ -159,6 +176,7 @@ def main():
         value = total * args.steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9
         st = env.episode_stats()
+        traffic, traffic_src = pmc_traffic(n_local)
         out = {
             "metric": "env-steps/sec at 65536 concurrent DemoMap games, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,7 +189,9 @@ def main():
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
                        "gathered_wins_all_ranks": list(gathered["wins"]) if gathered is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "achieved_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
+                         "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
         }
         if world == 1 and not args.no_cpu_baseline:

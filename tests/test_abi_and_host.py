@@ -1,0 +1,120 @@
+"""CPU tests (no GPU needed): the C-ABI library loads and exports every symbol include/evg.h declares, its
+default tables equal the oracle's independent restatement, evg_create fails loudly without a device (no CPU
+fallback), and the Python host logic mirrors the reference's interface."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def evg():
+    import everglades_amd
+    return everglades_amd
+
+
+def test_every_declared_symbol_is_exported(evg):
+    lib = evg.load_library()
+    header = open(os.path.join(ROOT, "include", "evg.h")).read()
+    declared = set(re.findall(r"\b(evg_[a-z_]+)\s*\(", header))
+    assert {"evg_create", "evg_step", "evg_reset", "evg_rollout_random", "evg_get_state", "evg_set_state"} <= declared
+    for name in sorted(declared):
+        assert hasattr(lib, name), "include/evg.h declares %s but libevg.so does not export it" % name
+    assert declared == set(evg._lib.EXPORTS), (declared ^ set(evg._lib.EXPORTS))
+    assert lib.evg_abi_version() == evg._lib.ABI_VERSION
+
+
+def test_default_tables_match_oracle_restatement(evg, oracle_mod):
+    a, b = evg.default_tables(), oracle_mod.demo_tables()
+    assert C.sizeof(a) == C.sizeof(b)
+    assert bytes(a) == bytes(b)
+    assert a.node_dist[3][6] == 3 and a.node_dist[6][3] == 3 and a.node_dist[1][3] == 0 and a.node_defense[3] == 1.75
+    assert [a.p1_node_map[i] for i in range(12)] == [0, 11, 8, 9, 10, 5, 6, 7, 2, 3, 4, 1]
+    assert [a.group_type[0][g] for g in range(12)] == [1, 2, 0] * 4 and a.group_size[1][11] == 12
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_create_fails_loudly_without_device(evg):
+    if _has_gpu():
+        pytest.skip("a HIP device is present")
+    lib = evg.load_library()
+    cfg = evg._lib.EvgConfig()
+    cfg.struct_size, cfg.abi_version, cfg.num_envs, cfg.device_id = C.sizeof(evg._lib.EvgConfig), evg._lib.ABI_VERSION, 4, 0
+    cfg.tables = evg.default_tables()
+    h = C.c_void_p()
+    rc = lib.evg_create(C.byref(cfg), C.byref(h))
+    assert rc == -2 and not h.value                              # EVG_ERR_NO_DEVICE
+    assert b"no CPU path" in lib.evg_last_error() or b"device" in lib.evg_last_error()
+    with pytest.raises(evg.EvgError):
+        evg.EvergladesVecEnv(4)                                   # the Python layer refuses too: no silent fallback
+    with pytest.raises(evg.EvgError):
+        evg.EvergladesEnv(seed=1).reset(players={0: None, 1: None})
+
+
+def test_config_abi_guard(evg):
+    lib = evg.load_library()
+    cfg = evg._lib.EvgConfig()
+    cfg.struct_size, cfg.abi_version, cfg.num_envs = 12, evg._lib.ABI_VERSION, 1
+    h = C.c_void_p()
+    assert lib.evg_create(C.byref(cfg), C.byref(h)) == -1        # EVG_ERR_INVALID before any device work
+    assert b"mismatch" in lib.evg_last_error()
+
+
+def test_tables_from_reference_schema_json(evg, tmp_path):
+    """A map/unit file pair in the reference's JSON schema (config/DemoMap.json, UnitDefinitions.json) parses to
+    the same tables as the built-in defaults."""
+    t = evg.default_tables()
+    nodes = []
+    for i in range(1, 12):
+        res = [name for name, bit in (("DEFENSE", 1), ("OBSERVE", 2)) if t.node_resource[i] & bit]
+        nodes.append({"ID": i, "Radius": 1.0, "Resource": res, "StructureDefense": t.node_defense[i],
+                      "ControlPoints": t.node_control_points[i], "TeamStart": t.node_team_start[i],
+                      "Connections": [{"ConnectedID": j, "Distance": t.node_dist[i][j]} for j in range(1, 12) if t.node_dist[i][j]]})
+    (tmp_path / "Map.json").write_text(json.dumps({"MapName": "Default", "nodes": nodes}))
+    units = [{"Name": n, "Health": t.unit_health[u], "Damage": t.unit_damage[u], "Speed": t.unit_speed[u],
+              "Control": t.unit_control[u], "Cost": t.unit_cost[u]} for u, n in enumerate(["Tank", "Controller", "Striker"])]
+    (tmp_path / "Units.json").write_text(json.dumps({"units": units}))
+    t2 = evg.tables_from_json("Map.json", "Units.json", config_dir=str(tmp_path) + "/")
+    assert bytes(t2) == bytes(t)
+    with pytest.raises(FileNotFoundError):
+        evg.tables_from_json("nope.json", None, config_dir=str(tmp_path))
+
+
+def test_canonical_actions_follow_the_server(evg):
+    ca = evg.canonical_actions
+    a = np.array([[3.9, 2.2], [1, 0], [11, 11.99], [0, 5], [5, 5], [6, 6], [7, 7], [8, 8], [9, 9]])
+    out = ca(a)
+    assert out.dtype == np.int32 and out.shape == (7, 2)
+    assert out.tolist() == [[3, 2], [1, 0], [11, 11], [0, 5], [5, 5], [6, 6], [7, 7]]        # first 7 rows, truncation
+    assert ca(np.zeros((3, 2))).tolist() == [[0, 0]] * 7                                      # padded with the invalid order
+    assert ca(np.array([[12, 1], [-1, 3], [3, 40]])).tolist()[:3] == [[12, 1], [-1, 3], [3, 12]]   # out of domain stays invalid
+    with pytest.raises(AssertionError):
+        ca(np.zeros((7, 3)))
+
+
+def test_single_env_constants_and_spaces(evg):
+    env = evg.EvergladesEnv(seed=3)
+    assert (env.num_turns, env.num_units, env.num_groups, env.num_nodes, env.num_actions_per_turn) == (150, 100, 12, 11, 7)
+    assert env.unit_classes == ["controller", "striker", "tank"]
+    assert env.observation_space.shape == (105,)
+    assert env.observation_space.low[0] == 1 and env.observation_space.high[0] == 151 and env.observation_space.high[4] == 100
+    v = evg.EvergladesVecEnv
+    assert (v.num_actions_per_turn, v.obs_len, v.num_groups) == (7, 105, 12)
+
+
+def test_shard_range_partitions(evg):
+    for total, world in [(524288, 8), (65536, 1), (10, 3), (7, 8)]:
+        spans = [evg.shard_range(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+            assert s0 + c0 == s1
+    assert evg.shard_range(524288, 8, 3) == (3 * 65536, 65536)

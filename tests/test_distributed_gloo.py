@@ -1,0 +1,72 @@
+"""CPU test of the N > 1 path with torch.distributed (gloo, world_size 2): envs are sharded by contiguous
+global id with no data-path collective, and the single gather of episode results reproduces what one process
+computes for all envs.  The shard results here come from the CPU oracle (the checker); on GPUs the same
+functions run on the HIP path's device tensors over RCCL (bench.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+TOTAL, SEED, TURNS = 96, 4711, 150
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rollout(n, first):
+    import oracle as om
+    om.lib().evo_set_num_threads(1)
+    o = om.Oracle(n, seed=SEED, env_id_base=first, auto_reset=True)
+    o.reset()
+    for _ in range(TURNS):
+        o.step(o.random_actions())
+    return o.episode_stats()
+
+
+def _worker(rank, world, port, outdir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import everglades_amd as evg
+    first, cnt = evg.shard_range(TOTAL, world, rank)
+    st = _rollout(cnt, first)
+    g = evg.gather_episode_results(torch.from_numpy(st["returns"]), torch.from_numpy(st["length"]), torch.from_numpy(st["winner"]), TOTAL)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), returns=g["returns"].numpy(), winner=g["winner"].numpy(),
+             length=g["length"].numpy(), wins=np.array(g["wins"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_rollout_gathers_to_single_process_result(tmp_path, oracle_mod, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ref = _rollout(TOTAL, 0)
+    for r in range(world):                       # all-gather: every rank holds the full result, in global env order
+        g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(g["winner"], ref["winner"]) and np.array_equal(g["length"], ref["length"])
+        assert np.array_equal(g["returns"], ref["returns"])
+        w = ref["winner"]
+        assert g["wins"].tolist() == [int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum())]
+        assert g["wins"][:3].sum() == TOTAL
+
+
+def test_gather_without_process_group_is_identity():
+    import everglades_amd as evg
+    r = torch.arange(10, dtype=torch.float32).reshape(5, 2)
+    g = evg.gather_episode_results(r, torch.full((5,), 150, dtype=torch.int32), torch.tensor([0, 1, 2, 0, -1], dtype=torch.int8))
+    assert torch.equal(g["returns"], r) and g["wins"] == (2, 1, 1, 1) and g["length"].tolist() == [150] * 5
