@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--obs-dtype", default="float32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -116,11 +117,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()      # one rank per GPU; wraps only in single-GPU rehearsals
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
     import everglades_amd as evg
 
     n_local = args.envs
@@ -135,7 +140,7 @@ def main():
     def barrier():
         torch.cuda.synchronize(device)
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[dev_index]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(device)
 
     def run(nsteps, timed):
@@ -167,7 +172,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     step_kernel_ms = kernel_ms_sum / args.steps

@@ -30,6 +30,9 @@ def gather_episode_results(returns, length, winner, total_envs=None, group=None)
     local = pack_episode_results(returns, length, winner)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+        home = local.device
+        if dist.get_backend(group) == "gloo" and local.is_cuda:
+            local = local.cpu()                   # gloo rehearsal of the RCCL path: collectives on host copies
         if total_envs is None:
             cnt = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
             dist.all_reduce(cnt, group=group)
@@ -41,7 +44,7 @@ def gather_episode_results(returns, length, winner, total_envs=None, group=None)
         padded[:local.shape[0]] = local
         parts = [torch.empty_like(padded) for _ in range(world)]
         dist.all_gather(parts, padded, group=group)           # ONE RCCL all-gather over xGMI
-        full = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+        full = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).to(home)
     else:
         full = local
     w = full[:, 2].to(torch.int64)
