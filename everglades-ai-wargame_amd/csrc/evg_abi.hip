@@ -172,6 +172,11 @@ static int build_dev_tables(const evg_config* cfg, DevTables* D) {
             D->cost_nib[p] |= (uint64_t)t.unit_cost[ty] << (4 * g);
         }
     for (int i = 1; i <= NN; ++i) D->p1inv_nib |= (uint64_t)i << (4 * t.p1_node_map[i]);
+    for (int n = 1; n <= NN; ++n) {
+        int best = 0;
+        for (int m = 1; m <= NN; ++m) if (t.node_dist[n][m] > 0) best = m;
+        D->maxnbr_nib |= (uint64_t)best << (4 * n);
+    }
 
     // observation of the game_init state (everglades_env.py:158-171 over server.py:382-501)
     for (int p = 0; p < NP; ++p) {
@@ -235,6 +240,8 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (!rc) rc = dev_alloc(h, &S.fin_len, N);
     if (!rc) rc = dev_alloc(h, &S.fin_win, N);
     if (!rc) rc = dev_alloc(h, &S.totals, 4);
+    if (!rc) rc = dev_alloc(h, &S.agent_cycle, 2 * N);
+    if (!rc) rc = dev_alloc(h, &S.agent_swarm, 2 * N);
     if (!rc) rc = dev_alloc(h, &h->d_tables, 1);
     if (rc) { evg_destroy(h); return rc; }
     S.T = h->d_tables;
@@ -251,6 +258,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     // every env starts in the game_init position; the episode counter is then set to -1 so that the
     // first evg_reset opens episode 0
     if (e == hipSuccess && launch_reset(S, nullptr, nullptr, cfg->obs_dtype, nullptr) != 0) e = hipGetLastError();
+    if (e == hipSuccess && launch_scripted_reset(S, nullptr) != 0) e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemset(S.episode, 0xFF, N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -307,6 +315,23 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     const int rc = launch_random_actions(h->S, actions_out, stream);
     if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream) {
+    if (!h || !obs || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
+    if (policy < EVG_POLICY_RANDOM || policy > EVG_POLICY_SWARM || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "policy/player out of range");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int rc = launch_scripted_actions(h->S, policy, player, obs, actions_out, h->cfg.obs_dtype, stream);
+    if (rc) return fail(EVG_ERR_HIP, "scripted_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_scripted_reset(evg_handle* h, void* stream) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int rc = launch_scripted_reset(h->S, stream);
+    if (rc) return fail(EVG_ERR_HIP, "scripted_reset launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
 

@@ -43,6 +43,7 @@ struct DevTables {
     uint64_t p1map_nib;          // nibble i = p1_node_map[i]
     uint64_t type_nib[2];        // nibble k = unit type of group k
     uint64_t speed_nib[2], control_nib[2], cost_nib[2];   // nibble k = speed / control / cost of group k's unit type
+    uint64_t maxnbr_nib;         // nibble n = highest-numbered neighbour of node n (SwarmAgent's next hop)
     uint64_t p1inv_nib;          // nibble n = slot of p1's board view that shows node n (inverse of p1_node_map)
     uint32_t damage_nib;         // nibble t = damage of unit type t
     uint32_t armor_byte;         // byte t   = health ("armor") of unit type t
@@ -68,6 +69,8 @@ struct DevState {
     int32_t*  fin_len;
     int8_t*   fin_win;
     unsigned long long* totals;
+    uint32_t* agent_cycle;       // [2][N] scripted-agent state: first_turn << 8 | group_num << 4 | node_num
+    uint32_t* agent_swarm;       // [2][N] SwarmAgent attack list, 8 nibbles
     uint32_t  seed_lo, seed_hi, env_id_base;
     const DevTables* T;
 };
@@ -91,5 +94,7 @@ struct StepIO {
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream);
 int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream);
 int launch_random_actions(const DevState& S, int32_t* actions, void* stream);
+int launch_scripted_actions(const DevState& S, int policy, int player, const void* obs, int32_t* actions, int obs_dtype, void* stream);
+int launch_scripted_reset(const DevState& S, void* stream);
 
 }  // namespace evg

@@ -767,6 +767,79 @@ __global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// scripted opponents (BASELINE config 5), one agent object per (env, player) that lives across
+// episodes like the reference's (evaluate.py:85-93):
+//   Cycle_BRush_Turn25 / Turn50   agents/State_Machine/cycle_rush_turn25.py:62-115 (constant 25 / 50)
+//   SwarmAgent                    agents/State_Machine/swarm_agent.py:66-102; np.random.shuffle of the
+//                                 module-global attack list -> keyed Fisher-Yates (oracle/rng_spec.py swarm_shuffle)
+// One thread per env; reads the player's observation row (turn, group locations, moving flags).
+// ---------------------------------------------------------------------------------------------
+template <typename OT>
+__global__ void __launch_bounds__(256) evg_scripted_actions_kernel(DevState S, int policy, int player, const OT* obs, int32_t* actions) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S.N) return;
+    const OT* o = obs + ((size_t)e * 2 + player) * OBS;
+    int2* out = reinterpret_cast<int2*>(actions) + ((size_t)e * 2 + player) * NA;
+    const int turn = (int)o[0];
+    int2 rows[NA];
+    if (policy == EVG_POLICY_RANDOM) {
+        gen_random_rows(S, S.env_id_base + (uint32_t)e, S.episode[e], turn, player, rows);
+    } else if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50) {
+        const int gate = policy == EVG_POLICY_CYCLE_RUSH_25 ? 25 : 50;
+        uint32_t st = S.agent_cycle[(size_t)player * S.N + e];     // bit 8 first_turn | group_num << 4 | node_num
+        int first = (int)((st >> 8) & 1u), group_num = (int)((st >> 4) & 15u), node_num = (int)(st & 15u);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int loc_i = (int)o[45 + 5 * i];
+            const bool issue = !first && ((loc_i != 11 && turn > gate) || turn < gate);   // :92 (Python precedence)
+            rows[i] = issue ? make_int2(group_num, node_num) : make_int2(0, 0);
+            if (issue) {
+                group_num = (group_num + 1) % NG;
+                if (group_num == 0) node_num = node_num % NN + 1;
+            }
+        }
+        S.agent_cycle[(size_t)player * S.N + e] = (uint32_t)node_num | ((uint32_t)group_num << 4);   // first_turn cleared, :73-76
+    } else {                                                       // EVG_POLICY_SWARM
+        uint32_t lst = S.agent_swarm[(size_t)player * S.N + e];    // attack list, 8 nibbles
+        const uint32_t env_id = S.env_id_base + (uint32_t)e, episode = S.episode[e];
+        const uint4 x0 = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_SWARM, 0u, turn, 0, player, 0);
+        const uint4 x1 = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_SWARM, 1u, turn, 0, player, 0);
+        const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {                              // i = 7 .. 1
+            const int i = 7 - k;
+            const int j = (int)__umulhi(w[k], (uint32_t)(i + 1));
+            const uint32_t x = ((lst >> (4 * i)) ^ (lst >> (4 * j))) & 15u;
+            lst ^= (x << (4 * i)) ^ (x << (4 * j));
+        }
+        S.agent_swarm[(size_t)player * S.N + e] = lst;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 1);    // np.tile([0, 1], (7, 1))
+        const uint64_t mx = S.T->maxnbr_nib;
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = (int)((lst >> (4 * k)) & 15u);
+            const bool idle = (int)o[48 + 5 * g] == 0;
+            const int pos = (int)o[45 + 5 * g];
+            const int2 r = make_int2(g, (int)((mx >> (4 * pos)) & 15u));   // max(NODE_CONNECTIONS[pos]), :97
+#pragma unroll
+            for (int i = 0; i < NA; ++i) rows[i] = (idle && n == i) ? r : rows[i];
+            n += (idle && n < NA) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) out[i] = rows[i];
+}
+
+__global__ void evg_scripted_reset_kernel(DevState S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * S.N) return;
+    S.agent_cycle[i] = 0x112u;             // first_turn = 1, group_num = 1, node_num = 2 (cycle_rush_turn25.py:49,56-57)
+    S.agent_swarm[i] = 0xBA875421u;        // ATTACK_LIST = [1,2,4,5,7,8,10,11] (swarm_agent.py:29), nibble k = entry k
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
@@ -790,6 +863,23 @@ int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtyp
         case EVG_OBS_I16: hipLaunchKernelGGL(evg_reset_kernel<int16_t>, grid, block, 0, s, S, mask, obs); break;
         default: return -1;
     }
+    return (int)hipGetLastError();
+}
+
+int launch_scripted_actions(const DevState& S, int policy, int player, const void* obs, int32_t* actions, int obs_dtype, void* stream) {
+    const dim3 grid((S.N + 255) / 256), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (obs_dtype) {
+        case EVG_OBS_F32: hipLaunchKernelGGL(evg_scripted_actions_kernel<float>, grid, block, 0, s, S, policy, player, (const float*)obs, actions); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL(evg_scripted_actions_kernel<double>, grid, block, 0, s, S, policy, player, (const double*)obs, actions); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL(evg_scripted_actions_kernel<int16_t>, grid, block, 0, s, S, policy, player, (const int16_t*)obs, actions); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_scripted_reset(const DevState& S, void* stream) {
+    hipLaunchKernelGGL(evg_scripted_reset_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S);
     return (int)hipGetLastError();
 }
 

@@ -136,6 +136,24 @@ class EvergladesVecEnv(object):
         _lib.check(self.L.evg_random_actions(self._h, self._ptr(out), self._stream()))
         return out
 
+    POLICIES = {"random": _lib.POLICY_RANDOM, "cycle_rush_turn25": _lib.POLICY_CYCLE_RUSH_25,
+                "cycle_rush_turn50": _lib.POLICY_CYCLE_RUSH_50, "swarm": _lib.POLICY_SWARM}
+
+    def scripted_actions(self, policy, player, obs=None, out=None):
+        """Orders of the on-device scripted agent `policy` ("random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm")
+        playing seat `player` in every env, from the observations `obs` (default: the env's own obs buffer).  Writes
+        rows [:, player] of `out` (default: the env's action buffer) and returns it.  Agent objects persist across
+        episodes like the reference's; scripted_reset() re-creates them."""
+        obs = self.obs if obs is None else obs
+        out = self._actions if out is None else out
+        pid = self.POLICIES[policy] if isinstance(policy, str) else int(policy)
+        assert obs.dtype == self.obs_dtype and obs.is_contiguous() and tuple(obs.shape) == (self.num_envs, 2, _lib.OBS_LEN)
+        _lib.check(self.L.evg_scripted_actions(self._h, pid, int(player), self._ptr(obs), self._ptr(out), self._stream()))
+        return out
+
+    def scripted_reset(self):
+        _lib.check(self.L.evg_scripted_reset(self._h, self._stream()))
+
     def rollout_random(self, steps, time_kernel=False, fused=True):
         """`steps` turns of random-vs-random play driven from native code (evg_rollout_random): per turn the
         on-device random_actions generator fills self._actions, then the step kernel runs (fused=True: the step kernel draws the same orders itself and stores them in

@@ -142,6 +142,18 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream);
  * (seed, env id, episode, turn, player).  actions_out: device int32 [N][2][7][2]. */
 int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream);
 
+/* Scripted opponents on the device (agents/State_Machine/): one agent object per (env, player), kept in the handle
+ * and alive across episodes like the reference's (evaluate.py:85-93).  Reads `player`'s rows of obs (device
+ * [N][2][105] of cfg.obs_dtype, as written by evg_step/evg_reset) and writes that player's 7 order rows of
+ * actions_out (device int32 [N][2][7][2]).
+ *   EVG_POLICY_RANDOM          random_actions.py:38-46 (same generator as evg_random_actions)
+ *   EVG_POLICY_CYCLE_RUSH_25   cycle_rush_turn25.py:62-115        EVG_POLICY_CYCLE_RUSH_50  cycle_rush_turn50.py
+ *   EVG_POLICY_SWARM           swarm_agent.py:66-102 (its list shuffle keyed like every other draw)
+ * evg_scripted_reset re-creates all agent objects (first_turn, cycling position, attack list). */
+enum { EVG_POLICY_RANDOM = 0, EVG_POLICY_CYCLE_RUSH_25 = 1, EVG_POLICY_CYCLE_RUSH_50 = 2, EVG_POLICY_SWARM = 3 };
+int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream);
+int evg_scripted_reset(evg_handle* h, void* stream);
+
 /* Rollout driver for random-vs-random play (the reference's demo/random_demo.py:90-113 loop with both
  * agents = random_actions): enqueues `steps` x (evg_random_actions into actions_buf, then evg_step) on
  * `stream` from native code, so that launch cost, not the Python interpreter, bounds small batches.

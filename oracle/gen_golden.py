@@ -354,6 +354,95 @@ def pack(games, metas, tmax=150):
 
 
 # ----------------------------------------------------------------------------------------------
+# scripted agents of BASELINE config 5, loaded from the reference by file path (they import only numpy)
+# ----------------------------------------------------------------------------------------------
+class _AgentRandomProxy(object):
+    """np.random for swarm_agent.py: shuffle(list) becomes the keyed Fisher-Yates of rng_spec.swarm_shuffle."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def shuffle(self, lst):
+        L = sys._getframe(1).f_locals
+        o = self._o
+        lst[:] = rng_spec.swarm_shuffle(o.seed, o.env_id, o.episode, int(L["obs"][0]), L["self"]._evg_player, lst)
+
+    def __getattr__(self, k):
+        return getattr(np.random, k)
+
+
+class _AgentNpProxy(object):
+    def __init__(self, owner):
+        self.random = _AgentRandomProxy(owner)
+
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+
+_agent_module_counter = [0]
+
+
+def load_agent(proxy, filename, classname, player):
+    """A fresh copy of the module per agent object, so the module-global ATTACK_LIST of swarm_agent.py is per agent."""
+    import importlib.util
+    _agent_module_counter[0] += 1
+    spec = importlib.util.spec_from_file_location("evg_ref_agent_%d" % _agent_module_counter[0],
+                                                  os.path.join(REF, "agents", "State_Machine", filename))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.np = _AgentNpProxy(proxy)
+    agent = getattr(mod, classname)(NA, player)
+    agent._evg_player = player
+    return agent
+
+
+AGENT_POLICY = {"Cycle_BRush_Turn25": 1, "Cycle_BRush_Turn50": 2, "SwarmAgent": 3}
+
+
+def play_agents(R, seats, seed, env_id, episodes):
+    """`episodes` consecutive games of one env; the two agent objects live across them (evaluate.py:85-93)."""
+    agents = [load_agent(R.proxy, fn, cn, p) for p, (fn, cn) in enumerate(seats)]
+    out = dict(obs=np.zeros((episodes, 151, 2, 105), np.int16), actions=np.zeros((episodes, 150, 2, 7, 2), np.int8),
+               length=np.zeros(episodes, np.int32), scores=np.zeros((episodes, 2), np.int32), status=np.zeros(episodes, np.uint8))
+    for ep in range(episodes):
+        obs = R.reset(seed, env_id, ep)
+        out["obs"][ep, 0] = np.stack([obs[0], obs[1]])
+        done, t = 0, 0
+        while not done:
+            acts = {p: np.array(agents[p].get_action(obs[p]), dtype=np.float64) for p in (0, 1)}
+            box = {}
+            game = R.env.game
+            orig = game.game_turn
+
+            def wrapped(actions, _o=orig, _b=box):
+                sc, st = _o(actions)
+                _b["scores"], _b["status"] = (int(sc[0]), int(sc[1])), int(st)
+                return sc, st
+
+            game.game_turn = wrapped
+            obs, reward, done, info = R.env.step(acts)
+            game.game_turn = orig
+            out["actions"][ep, t] = np.stack([canon_actions(acts[0]), canon_actions(acts[1])])
+            t += 1
+            out["obs"][ep, t] = np.stack([obs[0], obs[1]])
+        out["length"][ep], out["scores"][ep], out["status"][ep] = t, box["scores"], box["status"]
+    return out
+
+
+def gen_agent_fixtures(R):
+    cyc25, cyc50, swarm = ("cycle_rush_turn25.py", "Cycle_BRush_Turn25"), ("cycle_rush_turn50.py", "Cycle_BRush_Turn50"), ("swarm_agent.py", "SwarmAgent")
+    plans = [((cyc25, swarm), 31, 5), ((swarm, cyc25), 32, 9), ((cyc25, swarm), 33, 11), ((swarm, cyc25), 34, 2),
+             ((cyc50, swarm), 35, 4), ((swarm, swarm), 36, 6), ((cyc25, cyc25), 37, 8)]
+    games = [play_agents(R, seats, seed, env_id, 3) for seats, seed, env_id in plans]
+    d = dict(policy=np.array([[AGENT_POLICY[s[1]] for s in seats] for seats, _, _ in plans], np.int32),
+             seed=np.array([p[1] for p in plans], np.uint64), env_id=np.array([p[2] for p in plans], np.uint32))
+    for k in games[0]:
+        d[k] = np.stack([g[k] for g in games])
+    np.savez_compressed(os.path.join(OUT, "agents_scripted.npz"), **d)
+    print("agents:", d["length"].tolist(), d["status"].tolist(), flush=True)
+
+
+# ----------------------------------------------------------------------------------------------
 def kat_script():
     """deterministic no-combat trajectory."""
     z = np.zeros((7, 2))
@@ -390,6 +479,9 @@ def main():
     t0 = time.time()
     R = Runner()
     stats = {}
+    if os.environ.get("EVG_GOLDEN_ONLY") == "agents":
+        gen_agent_fixtures(R)
+        return
 
     # 1. full-state trajectories, several policies
     plan = [("random", 6), ("wild", 6), ("rush", 4), ("brawl", 4), ("brawl_v_random", 4), ("rush_v_random", 4)]
@@ -414,6 +506,9 @@ def main():
     assert g["status"][g["length"] - 1] == 3, g["status"]
     np.savez_compressed(os.path.join(OUT, "edit_annihilation.npz"),
                         **pack([g], [dict(policy="edit", seed=5, env_id=3, episode=0)], tmax=3))
+
+    # 3b. scripted agents of BASELINE config 5 (the reference's own agent classes produce the action streams)
+    gen_agent_fixtures(R)
 
     # 4. bulk random-vs-random: outcomes + per-turn checksums only
     B = 120

@@ -82,6 +82,8 @@ def lib():
         L.evo_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.evo_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.evo_observe.argtypes = [C.c_void_p, C.c_void_p]
+        L.evo_scripted_actions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.evo_scripted_reset.argtypes = [C.c_void_p]
         L.evo_episode_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.evo_combat_draw.restype = C.c_int
         L.evo_combat_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -143,6 +145,18 @@ class Oracle(object):
         a = np.zeros((self.n, NP, NA, 2), np.int32)
         self.L.evo_random_actions(self.h, _p(a))
         return a
+
+    def scripted_actions(self, policy, player, obs, out=None):
+        """policy: 1 Cycle_BRush_Turn25, 2 Cycle_BRush_Turn50, 3 SwarmAgent; writes rows [:, player] of `out`."""
+        o = np.ascontiguousarray(obs, np.float64)
+        assert o.shape == (self.n, NP, OBS)
+        if out is None:
+            out = np.zeros((self.n, NP, NA, 2), np.int32)
+        self.L.evo_scripted_actions(self.h, int(policy), int(player), _p(o), _p(out))
+        return out
+
+    def scripted_reset(self):
+        self.L.evo_scripted_reset(self.h)
 
     def observe(self):
         obs = np.zeros((self.n, NP, OBS), np.float64)

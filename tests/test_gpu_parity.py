@@ -241,3 +241,55 @@ def test_native_rollout_fused_equals_stepwise(evg, oracle_mod):
     ms = a.rollout_random(10, time_kernel=True)[-1]
     assert ms > 0
     a.close(); b.close()
+
+
+def test_scripted_agents_golden_through_abi(evg):
+    """The on-device scripted agents + the HIP env replay what the reference's agent classes and server did
+    (tests/golden/agents_scripted.npz): three consecutive episodes per env, agent objects alive across them."""
+    d = load_golden("agents_scripted.npz")
+    G, E = d["length"].shape
+    for g in range(G):
+        env = evg.EvergladesVecEnv(1, seed=int(d["seed"][g]), env_id_base=int(d["env_id"][g]), obs_dtype="float64", auto_reset=False)
+        pol = [int(x) for x in d["policy"][g]]
+        for ep in range(E):
+            obs = env.reset()
+            for t in range(int(d["length"][g, ep])):
+                assert np.array_equal(_np(obs)[0], d["obs"][g, ep, t].astype(np.float64)), (g, ep, t)
+                env.scripted_actions(pol[0], 0)
+                a = env.scripted_actions(pol[1], 1)
+                assert np.array_equal(_np(a)[0], d["actions"][g, ep, t]), ("orders", g, ep, t)
+                obs, rew, done, info = env.step(a)
+            assert int(done[0]) == 1 and int(info["status"][0]) == d["status"][g, ep]
+            assert np.array_equal(_np(info["scores"])[0], d["scores"][g, ep])
+        env.close()
+
+
+@pytest.mark.parametrize("N,seats", [(1024, ("cycle_rush_turn25", "swarm")), (1024, ("swarm", "cycle_rush_turn50")), (65536, ("cycle_rush_turn25", "swarm"))])
+def test_config5_scripted_rollout_vs_oracle(evg, oracle_mod, N, seats):
+    """BASELINE config 5: cycle_base_rush vs swarm_agent action streams with auto-reset (games end by BaseCapture
+    around turn 85-95, so envs desynchronise).  Device agents + HIP env == oracle agents + oracle env; at 65 536
+    envs the oracle follows a 512-env sub-range with the same global env ids."""
+    seed, steps = 515, 260
+    lo, n = (0, N) if N <= 1024 else (40000, 512)
+    pid = [evg.EvergladesVecEnv.POLICIES[s] for s in seats]
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    ora = oracle_mod.Oracle(n, seed=seed, env_id_base=lo, auto_reset=True)
+    obs = env.reset()
+    o_obs = ora.reset()
+    for t in range(steps):
+        env.scripted_actions(seats[0], 0)
+        a = env.scripted_actions(seats[1], 1)
+        oa = np.zeros((n, 2, 7, 2), np.int32)
+        ora.scripted_actions(pid[0], 0, o_obs, oa)
+        ora.scripted_actions(pid[1], 1, o_obs, oa)
+        assert np.array_equal(_np(a[lo:lo + n]), oa), ("orders", t)
+        obs, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(oa)
+        assert np.array_equal(_np(obs[lo:lo + n]).astype(np.float64), o_obs), ("obs", t)
+        assert np.array_equal(_np(info["scores"][lo:lo + n]), o_info["scores"]) and np.array_equal(_np(done[lo:lo + n]), o_done)
+    st, ost = env.episode_stats(), ora.episode_stats()
+    assert np.array_equal(st["winner"][lo:lo + n], ost["winner"]) and np.array_equal(st["length"][lo:lo + n], ost["length"])
+    assert st["totals"][0] >= 2 * N and ost["totals"][0] >= 2 * n          # at least two finished episodes per env
+    if seats[0] == "cycle_rush_turn25":
+        assert st["totals"][1] > 0.95 * st["totals"][0]                     # the cycling base rush wins (SURVEY App. D)
+    env.close()

@@ -1,0 +1,29 @@
+"""CPU test: the oracle's restatement of the scripted agents of BASELINE config 5 (Cycle_BRush_Turn25/50,
+SwarmAgent) reproduces, order by order, what the reference's own agent classes emitted in
+tests/golden/agents_scripted.npz -- three consecutive episodes per env with the agent objects kept alive,
+as evaluate.py:85-93 does -- while the oracle env reproduces the observations they were computed from."""
+import numpy as np
+
+from conftest import load_golden
+
+
+def test_scripted_agents_match_reference(oracle_mod):
+    d = load_golden("agents_scripted.npz")
+    G, E = d["length"].shape
+    assert set(d["status"][:4].ravel()) == {2}            # cycle rush vs swarm always ends by BaseCapture
+    for g in range(G):
+        o = oracle_mod.Oracle(1, seed=int(d["seed"][g]), env_id_base=int(d["env_id"][g]))
+        pol = d["policy"][g]
+        for ep in range(E):
+            obs = o.reset()
+            assert o.get_state()["env"][0, 2] == ep
+            T = int(d["length"][g, ep])
+            for t in range(T):
+                assert np.array_equal(obs[0], d["obs"][g, ep, t].astype(np.float64)), (g, ep, t)
+                a = np.zeros((1, 2, 7, 2), np.int32)
+                o.scripted_actions(int(pol[0]), 0, obs, a)
+                o.scripted_actions(int(pol[1]), 1, obs, a)
+                assert np.array_equal(a[0], d["actions"][g, ep, t]), ("orders", g, ep, t, a[0].tolist(), d["actions"][g, ep, t].tolist())
+                obs, rew, done, info = o.step(a)
+            assert done[0] == 1 and info["status"][0] == d["status"][g, ep] and np.array_equal(info["scores"][0], d["scores"][g, ep])
+            assert np.array_equal(obs[0], d["obs"][g, ep, T].astype(np.float64))
