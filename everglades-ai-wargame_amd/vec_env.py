@@ -68,14 +68,18 @@ class EvergladesVecEnv(object):
             self.scores = torch.zeros((N, 2), dtype=torch.int32, device=self.device)
             self.status = torch.zeros((N,), dtype=torch.uint8, device=self.device)
             self._actions = torch.zeros((N, 2, _lib.NUM_ACTIONS, 2), dtype=torch.int32, device=self.device)
+        # per-call fast path: raw pointers of the env's own buffers, the info dict and the raw-stream getter are cached
+        self._p = {k: C.c_void_p(getattr(self, k).data_ptr()) for k in ("obs", "reward", "done", "winner", "scores", "status")}
+        self._info = dict(winner=self.winner, scores=self.scores, status=self.status)
+        self._act_shape = (N, 2, _lib.NUM_ACTIONS, 2)
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._int32 = torch.int32
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
-        torch = _torch()
-        try:        # fast path: raw hipStream_t of torch's current stream without building a Stream object
-            return C.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
-        except AttributeError:
-            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if self._raw_stream is not None:        # raw hipStream_t of torch's current stream without building a Stream object
+            return C.c_void_p(self._raw_stream(self.device.index))
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
     @staticmethod
     def _ptr(t):
@@ -121,10 +125,16 @@ class EvergladesVecEnv(object):
         """One turn of every game.  Returns (obs [N,2,105], reward [N,2] f32, done [N] u8, info) where info has
         winner [N] i8, scores [N,2] i32, status [N] u8 (everglades_env.py:32-73).  The tensors are the env's own
         output buffers and are overwritten by the next call."""
-        a = self._as_actions(actions)
-        _lib.check(self.L.evg_step(self._h, self._ptr(a), self._ptr(self.obs), self._ptr(self.reward), self._ptr(self.done),
-                                   self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status), self._stream()))
-        return self.obs, self.reward, self.done, dict(winner=self.winner, scores=self.scores, status=self.status)
+        a = actions
+        if not (type(a) is _torch().Tensor and a.dtype is self._int32 and a.device == self.device and a.shape == self._act_shape
+                and a.is_contiguous()):
+            a = self._as_actions(actions)
+        p = self._p
+        rc = self.L.evg_step(self._h, C.c_void_p(a.data_ptr()), p["obs"], p["reward"], p["done"], p["winner"], p["scores"], p["status"],
+                             self._stream())
+        if rc:
+            _lib.check(rc)
+        return self.obs, self.reward, self.done, self._info
 
     def observe(self):
         _lib.check(self.L.evg_observe(self._h, self._ptr(self.obs), self._stream()))
