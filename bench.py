@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--obs-dtype", default="float32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="random", choices=["random", "scripted"],
+                    help="random: BASELINE metric config (random vs random); scripted: BASELINE config 5 (cycle_rush_turn25 vs swarm)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
@@ -153,7 +155,8 @@ def main():
         left = nsteps
         while left > 0:
             chunk = min(left, period - turn_counter % period)
-            out = env.rollout_random(chunk, time_kernel=timed)
+            out = (env.rollout_random(chunk, time_kernel=timed) if args.workload == "random" else
+                   env.rollout_policies(chunk, "cycle_rush_turn25", "swarm", time_kernel=timed))
             if timed:
                 kernel_ms_sum += out[-1] * chunk
             turn_counter += chunk
@@ -187,8 +190,10 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": "%d concurrent DemoMap games per GPU, random_actions vs random_actions drawn on device (fused into the "
-                                   "step kernel, orders written to an [N,2,7,2] tensor), auto-reset, obs %s [N,2,105]" % (n_local, args.obs_dtype),
+            "config": {"workload": ("%d concurrent DemoMap games per GPU, random_actions vs random_actions drawn on device (fused into the "
+                                    "step kernel, orders written to an [N,2,7,2] tensor), auto-reset, obs %s [N,2,105]" if args.workload == "random" else
+                                    "%d concurrent DemoMap games per GPU, on-device Cycle_BRush_Turn25 vs SwarmAgent (BASELINE config 5; episodes end by "
+                                    "BaseCapture after 84-94 turns), auto-reset, obs %s [N,2,105]") % (n_local, args.obs_dtype),
                        "envs_per_gpu": n_local, "total_envs": total, "parallelism": "env-sharded x%d" % world,
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],

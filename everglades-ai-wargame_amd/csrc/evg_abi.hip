@@ -335,8 +335,26 @@ int evg_scripted_reset(evg_handle* h, void* stream) {
     return EVG_OK;
 }
 
+static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
+                        uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream);
+
 int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf, void* obs_out, float* reward_out, uint8_t* done_out,
                        int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
+    return rollout_impl(h, steps, fused, EVG_POLICY_RANDOM, EVG_POLICY_RANDOM, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out,
+                        status_out, step_kernel_ms, stream);
+}
+
+int evg_rollout_policies(evg_handle* h, int steps, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
+                         uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
+    if (policy0 < EVG_POLICY_RANDOM || policy0 > EVG_POLICY_SWARM || policy1 < EVG_POLICY_RANDOM || policy1 > EVG_POLICY_SWARM)
+        return fail(EVG_ERR_INVALID, "policy out of range");
+    if (!obs_out) return fail(EVG_ERR_INVALID, "rollout_policies: obs_out is required (the agents read it)");
+    return rollout_impl(h, steps, 0, policy0, policy1, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out,
+                        step_kernel_ms, stream);
+}
+
+static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
+                        uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (steps < 1 || !actions_buf || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, actions_buf, reward_out, done_out required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
@@ -352,8 +370,14 @@ int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf
     }
     StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? 1 : 0, actions_buf, h->stamps, h->ablate};
     for (int i = 0; i < steps; ++i) {
-        int rc = fused ? 0 : launch_random_actions(h->S, actions_buf, stream);
-        if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
+        int rc = 0;
+        if (policy0 == EVG_POLICY_RANDOM && policy1 == EVG_POLICY_RANDOM) {
+            if (!fused) rc = launch_random_actions(h->S, actions_buf, stream);
+        } else {                                  // the agents read the observations of the previous turn from obs_out
+            rc = launch_scripted_actions(h->S, policy0, 0, obs_out, actions_buf, h->cfg.obs_dtype, stream);
+            if (!rc) rc = launch_scripted_actions(h->S, policy1, 1, obs_out, actions_buf, h->cfg.obs_dtype, stream);
+        }
+        if (rc) return fail(EVG_ERR_HIP, "action kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         const bool sample = step_kernel_ms && i % kSampleEvery == 0;
         if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery)], s));
         rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);

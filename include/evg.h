@@ -166,6 +166,13 @@ int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf
                        uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
                        float* step_kernel_ms, void* stream);
 
+/* The same driver for any pair of on-device policies (EVG_POLICY_*; BASELINE config 5 is CYCLE_RUSH_25 vs SWARM): per
+ * turn two agent launches read the previous observations in obs_out (which must hold the current observations when
+ * the call starts, e.g. from evg_reset) and one step launch follows. */
+int evg_rollout_policies(evg_handle* h, int steps, int policy0, int policy1, int32_t* actions_buf, void* obs_out,
+                         float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
+                         float* step_kernel_ms, void* stream);
+
 /* Canonical state exchange (host order; used by parity tests and to load golden positions).
  * All pointers are HOST pointers; the call synchronises.  Any pointer may be NULL.
  *   groups int32 [N][2][12][8]: location, travel_destination (-1 none), distance_remaining, ready,

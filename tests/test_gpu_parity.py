@@ -293,3 +293,48 @@ def test_config5_scripted_rollout_vs_oracle(evg, oracle_mod, N, seats):
     if seats[0] == "cycle_rush_turn25":
         assert st["totals"][1] > 0.95 * st["totals"][0]                     # the cycling base rush wins
     env.close()
+
+
+def test_turn_can_be_captured_in_a_hip_graph(evg, oracle_mod):
+    """step()/random_actions() only enqueue on the caller's stream (no allocation, no synchronisation), so a whole
+    turn can be captured with torch.cuda.graph and replayed; the replayed turns equal the oracle's."""
+    import torch
+    N, seed = 200, 5
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset(); ora.reset()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            env.step(env.random_actions())
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        env.step(env.random_actions())
+    for _ in range(2):                      # the two warm-up turns; the captured turn itself is not executed by the capture
+        o_obs, _, _, o_info = ora.step(ora.random_actions())
+    for t in range(40):
+        g.replay()
+        o_obs, _, o_done, o_info = ora.step(ora.random_actions())
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs) and np.array_equal(_np(env.scores), o_info["scores"])
+    check_state(env, ora.get_state(), "graph replay")
+    env.close()
+
+
+def test_native_policy_rollout_equals_stepwise(evg):
+    N, seed, steps = 300, 12, 200
+    a = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    b = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    a.reset(); b.reset()
+    a.rollout_policies(steps, "cycle_rush_turn25", "swarm")
+    for t in range(steps):
+        b.scripted_actions("cycle_rush_turn25", 0)
+        b.step(b.scripted_actions("swarm", 1))
+    assert np.array_equal(_np(a.obs), _np(b.obs)) and np.array_equal(_np(a._actions), _np(b._actions))
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(a.episode_stats()["totals"], b.episode_stats()["totals"]) and a.episode_stats()["totals"][0] > N
+    a.close(); b.close()
