@@ -15,7 +15,7 @@ OBS_F32, OBS_F64, OBS_I16 = 0, 1, 2
 ABI_VERSION = 1
 POLICY_RANDOM, POLICY_CYCLE_RUSH_25, POLICY_CYCLE_RUSH_50, POLICY_SWARM = 0, 1, 2, 3
 
-EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
+EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_fog_of_war", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
            "evg_get_state", "evg_set_state", "evg_episode_stats", "evg_episode_stats_device", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
@@ -73,6 +73,7 @@ def load():
     L.evg_reset.argtypes = [vp, vp, vp, vp]
     L.evg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.evg_observe.argtypes = [vp, vp, vp]
+    L.evg_fog_of_war.argtypes = [vp, vp, vp]
     L.evg_random_actions.argtypes = [vp, vp, vp]
     L.evg_rollout_random.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]
     L.evg_rollout_policies.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]

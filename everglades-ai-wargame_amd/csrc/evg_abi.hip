@@ -176,6 +176,7 @@ static int build_dev_tables(const evg_config* cfg, DevTables* D) {
         int best = 0;
         for (int m = 1; m <= NN; ++m) if (t.node_dist[n][m] > 0) best = m;
         D->maxnbr_nib |= (uint64_t)best << (4 * n);
+        for (int m = 1; m <= NN; ++m) if (t.node_dist[n][m] > 0) D->nbr_mask[n] |= 1u << m;
     }
 
     // observation of the game_init state (everglades_env.py:158-171 over server.py:382-501)
@@ -324,6 +325,14 @@ int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs,
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     const int rc = launch_scripted_actions(h->S, policy, player, obs, actions_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "scripted_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, void* stream) {
+    if (!h || !fog_out) return fail(EVG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int rc = launch_fog(h->S, fog_out, stream);
+    if (rc) return fail(EVG_ERR_HIP, "fog launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
 

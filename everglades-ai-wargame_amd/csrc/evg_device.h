@@ -43,6 +43,7 @@ struct DevTables {
     uint64_t p1map_nib;          // nibble i = p1_node_map[i]
     uint64_t type_nib[2];        // nibble k = unit type of group k
     uint64_t speed_nib[2], control_nib[2], cost_nib[2];   // nibble k = speed / control / cost of group k's unit type
+    uint32_t nbr_mask[12];       // bit m of entry n: node m is connected to node n
     uint64_t maxnbr_nib;         // nibble n = highest-numbered neighbour of node n (SwarmAgent's next hop)
     uint64_t p1inv_nib;          // nibble n = slot of p1's board view that shows node n (inverse of p1_node_map)
     uint32_t damage_nib;         // nibble t = damage of unit type t
@@ -96,5 +97,6 @@ int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtyp
 int launch_random_actions(const DevState& S, int32_t* actions, void* stream);
 int launch_scripted_actions(const DevState& S, int policy, int player, const void* obs, int32_t* actions, int obs_dtype, void* stream);
 int launch_scripted_reset(const DevState& S, void* stream);
+int launch_fog(const DevState& S, uint8_t* out, void* stream);
 
 }  // namespace evg

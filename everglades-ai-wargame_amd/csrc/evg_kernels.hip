@@ -840,6 +840,33 @@ __global__ void evg_scripted_reset_kernel(DevState S) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// fog-of-war mask of board_state (server.py:402-425): the reference computes `valid_nodes` and never
+// applies it; exposed here as an optional observation plane.  One thread per (env, player); real node order.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2 * S.N) return;
+    const int e = idx >> 1, p = idx & 1;
+    const size_t N = (size_t)S.N;
+    const DevTables* __restrict__ T = S.T;
+    uint32_t valid = 0;
+#pragma unroll
+    for (int n = 1; n <= NN; ++n) {
+        const int cb = (int)((S.node[(size_t)(n - 1) * N + e] >> 10) & 3u) - 1;
+        if (cb == p) valid |= (1u << n) | ((T->resource[n] & EVG_RES_OBSERVE) ? T->nbr_mask[n] : 0u);   // :411-418
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {                                                                      // :421-424
+        const uint32_t w = S.grp[(size_t)(p * 12 + k) * N + e];
+        const bool listed_idle = (w & G_MASK_M) != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;
+        valid |= (listed_idle ? 1u : 0u) << (w & G_LOC_M);
+    }
+    uint8_t* o = out + (size_t)idx * NN;
+#pragma unroll
+    for (int n = 1; n <= NN; ++n) o[n - 1] = (uint8_t)((valid >> n) & 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
@@ -880,6 +907,11 @@ int launch_scripted_actions(const DevState& S, int policy, int player, const voi
 
 int launch_scripted_reset(const DevState& S, void* stream) {
     hipLaunchKernelGGL(evg_scripted_reset_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S);
+    return (int)hipGetLastError();
+}
+
+int launch_fog(const DevState& S, uint8_t* out, void* stream) {
+    hipLaunchKernelGGL(evg_fog_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, out);
     return (int)hipGetLastError();
 }
 

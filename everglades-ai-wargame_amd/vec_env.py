@@ -140,6 +140,16 @@ class EvergladesVecEnv(object):
         _lib.check(self.L.evg_observe(self._h, self._ptr(self.obs), self._stream()))
         return self.obs
 
+    def fog_of_war(self, out=None):
+        """uint8 [N, 2, 11]: the fog-of-war mask the reference computes in board_state and discards (server.py:402-425)."""
+        torch = _torch()
+        if out is None:
+            if getattr(self, "_fog", None) is None:
+                self._fog = torch.zeros((self.num_envs, 2, _lib.NUM_NODES), dtype=torch.uint8, device=self.device)
+            out = self._fog
+        _lib.check(self.L.evg_fog_of_war(self._h, self._ptr(out), self._stream()))
+        return out
+
     def random_actions(self, out=None):
         """On-device equivalent of agents/State_Machine/random_actions.py for both players of every env."""
         out = self._actions if out is None else out

@@ -137,6 +137,12 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
  * the board_state/player_state half of step (server.py:382-501). obs_out as in evg_step. */
 int evg_observe(evg_handle* h, void* obs_out, void* stream);
 
+/* Fog-of-war plane of the current state: the `valid_nodes` mask that board_state computes and then never applies
+ * (server.py:402-425).  fog_out: device uint8 [N][2][11], entry [e][p][i] = 1 iff player p sees node ID i+1 (a node
+ * it controls, a neighbour of a controlled OBSERVE node, or a node where it has a non-moving group).  Real node
+ * order, not mirrored for player 1, exactly as the reference computes it. */
+int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, void* stream);
+
 /* Input generator for the benchmark configs: the on-device equivalent of
  * agents/State_Machine/random_actions.py:38-46 for every env and both players, keyed by
  * (seed, env id, episode, turn, player).  actions_out: device int32 [N][2][7][2]. */

@@ -117,6 +117,30 @@ def load_reference():
 GF_LOC, GF_DEST, GF_DIST, GF_READY, GF_MOVING, GF_DESTROYED, GF_COUNT, GF_STAMP = range(8)
 
 
+class FogTap(object):
+    """Captures the local `valid_nodes` of EvergladesGame.board_state (server.py:402-425: the fog-of-war mask the
+    reference computes and then never applies) with a profiler hook on the function's return."""
+
+    def __init__(self):
+        self.last = {}
+
+    def _hook(self, frame, event, arg):
+        if event == "return" and frame.f_code.co_name == "board_state":
+            L = frame.f_locals
+            if "valid_nodes" in L:
+                self.last[int(L["player_num"])] = [int(bool(v)) for v in L["valid_nodes"]]
+
+    def __enter__(self):
+        sys.setprofile(self._hook)
+        return self
+
+    def __exit__(self, *a):
+        sys.setprofile(None)
+
+    def snapshot(self):
+        return np.array([self.last[0], self.last[1]], np.uint8)
+
+
 class Tracker(object):
     """Follows one reference game and dumps the canonical state (tests/README of the layout:
     groups[2][12][8] = loc,dest,dist,ready,moving,destroyed,count,stamp; nodes[11][2] =
@@ -283,17 +307,19 @@ class Runner(object):
 
     def play(self, policy, seed, env_id, episode=0, full=True, pre_edit=None, script=None, max_turns=400):
         """Returns a dict of per-turn arrays.  `script`: optional list of (a0, a1) overriding the policy."""
-        obs = self.reset(seed, env_id, episode)
-        game = self.env.game
-        if pre_edit is not None:
-            pre_edit(game)
+        tap = FogTap()
+        with tap:
+            obs = self.reset(seed, env_id, episode)
+            game = self.env.game
+            if pre_edit is not None:
+                pre_edit(game)
             obs = self.env._build_observations()
         tr = Tracker(game)
         ctx = [dict(seed=seed, env_id=env_id, episode=episode, nprng=np.random.default_rng([seed, env_id, p]))
                for p in (0, 1)]
         pols = POLICIES[policy] if policy in POLICIES else (pol_zero, pol_zero)
         rec = dict(obs=[np.stack([obs[0], obs[1]])], actions=[], raw0=[], raw1=[], reward=[], done=[], scores=[],
-                   status=[], groups=[], nodes=[], health=[], rank=[])
+                   status=[], groups=[], nodes=[], health=[], rank=[], fog=[tap.snapshot()])
         g, n, h, r = tr.snapshot()
         rec["groups"].append(g), rec["nodes"].append(n), rec["health"].append(h), rec["rank"].append(r)
         done, t = 0, 0
@@ -312,8 +338,10 @@ class Runner(object):
                 return s, st
 
             game.game_turn = wrapped
-            obs, reward, done, info = self.env.step({0: a0, 1: a1})
+            with tap:
+                obs, reward, done, info = self.env.step({0: a0, 1: a1})
             game.game_turn = orig
+            rec["fog"].append(tap.snapshot())
             tr.after_turn()
             t += 1
             rec["actions"].append(np.stack([canon_actions(a0), canon_actions(a1)]))
@@ -325,7 +353,7 @@ class Runner(object):
             g, n, h, r = tr.snapshot()
             rec["groups"].append(g), rec["nodes"].append(n), rec["health"].append(h), rec["rank"].append(r)
         out = dict(length=t)
-        for k in ("obs", "actions", "reward", "done", "scores", "status", "groups", "nodes", "health", "rank"):
+        for k in ("obs", "actions", "reward", "done", "scores", "status", "groups", "nodes", "health", "rank", "fog"):
             out[k] = np.array(rec[k])
         assert np.all(out["obs"] == np.round(out["obs"])) and np.abs(out["obs"]).max() <= 500
         return out
@@ -342,13 +370,14 @@ def pack(games, metas, tmax=150):
         reward=np.zeros((G, tmax, 2), np.float64), done=np.zeros((G, tmax), np.uint8),
         scores=np.zeros((G, tmax, 2), np.int32), status=np.zeros((G, tmax), np.uint8),
         groups=np.zeros((G, tmax + 1, 2, NG, 8), np.int16), nodes=np.zeros((G, tmax + 1, NN, 2), np.int16),
-        health=np.zeros((G, tmax + 1, 2, NU), np.float64), rank=np.zeros((G, tmax + 1, 2, NG), np.int8))
+        health=np.zeros((G, tmax + 1, 2, NU), np.float64), rank=np.zeros((G, tmax + 1, 2, NG), np.int8),
+        fog=np.zeros((G, tmax + 1, 2, NN), np.uint8))
     for i, g in enumerate(games):
         T = g["length"]
         d["obs"][i, :T + 1] = g["obs"]
         for k in ("actions", "reward", "done", "scores", "status"):
             d[k][i, :T] = g[k]
-        for k in ("groups", "nodes", "health", "rank"):
+        for k in ("groups", "nodes", "health", "rank", "fog"):
             d[k][i, :T + 1] = g[k]
     return d
 

@@ -82,6 +82,7 @@ def lib():
         L.evo_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.evo_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.evo_observe.argtypes = [C.c_void_p, C.c_void_p]
+        L.evo_fog_of_war.argtypes = [C.c_void_p, C.c_void_p]
         L.evo_scripted_actions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.evo_scripted_reset.argtypes = [C.c_void_p]
         L.evo_episode_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
@@ -157,6 +158,11 @@ class Oracle(object):
 
     def scripted_reset(self):
         self.L.evo_scripted_reset(self.h)
+
+    def fog_of_war(self):
+        f = np.zeros((self.n, NP, NN), np.uint8)
+        self.L.evo_fog_of_war(self.h, _p(f))
+        return f
 
     def observe(self):
         obs = np.zeros((self.n, NP, OBS), np.float64)
