@@ -201,6 +201,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "achieved_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
+                         "measured_traffic_GBps": (traffic / (step_kernel_ms * 1e-3) / 1e9) if traffic else None,
+                         "note": "achieved uses the ALGORITHMIC bytes of SURVEY 8(d); it exceeds 1.0 of peak when the kernel moves fewer "
+                                 "bytes than that accounting (health rows are only touched where combat hits): compare traffic",
                          "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
         }

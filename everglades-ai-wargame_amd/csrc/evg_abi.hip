@@ -49,6 +49,7 @@ struct evg_handle {
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
     uint32_t ablate = 0;                // EVG_ABLATE (diagnostic)
+    int32_t lanes = 64;                 // step-kernel variant (EVG_LANES=32|64 overrides the default)
     unsigned long long* stamps = nullptr;   // diagnostic build only
 };
 
@@ -220,6 +221,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     evg_handle* h = new evg_handle();
     h->cfg = *cfg;
     if (const char* ab = getenv("EVG_ABLATE")) h->ablate = (uint32_t)strtoul(ab, nullptr, 0);
+    if (const char* ln = getenv("EVG_LANES")) h->lanes = atoi(ln) == 32 ? 32 : 64;
     int rc = build_dev_tables(cfg, &h->host_tables);
     if (rc != EVG_OK) { delete h; return rc; }
     const size_t N = (size_t)cfg->num_envs;
@@ -247,7 +249,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (rc) { evg_destroy(h); return rc; }
     S.T = h->d_tables;
 #ifdef EVG_STAMPS
-    if (!rc) rc = dev_alloc(h, &h->stamps, (size_t)((cfg->num_envs + WG / 2 - 1) / (WG / 2)) * 16);
+    if (!rc) rc = dev_alloc(h, &h->stamps, (size_t)((cfg->num_envs + 15) / 16) * 16);
     if (rc) { evg_destroy(h); return rc; }
 #endif
     hipError_t e = hipMemcpy(h->d_tables, &h->host_tables, sizeof(DevTables), hipMemcpyHostToDevice);
@@ -296,7 +298,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, nullptr, h->stamps, h->ablate};
+    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, nullptr, h->stamps, h->lanes, h->ablate};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -305,7 +307,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
 int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, 0};
+    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, h->lanes, 0};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -377,7 +379,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         HIP_TRY(hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? 1 : 0, actions_buf, h->stamps, h->ablate};
+    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? 1 : 0, actions_buf, h->stamps, h->lanes, h->ablate};
     for (int i = 0; i < steps; ++i) {
         int rc = 0;
         if (policy0 == EVG_POLICY_RANDOM && policy1 == EVG_POLICY_RANDOM) {
@@ -512,7 +514,7 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
 int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, h->stamps, (size_t)((h->S.N + WG / 2 - 1) / (WG / 2)) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, h->stamps, (size_t)((h->S.N + 15) / 16) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return EVG_OK;
 }
 #endif

@@ -3,16 +3,19 @@
 // One fused kernel per env-step replaces EvergladesEnv.step -> EvergladesGame.game_turn ->
 // board_state/player_state of the reference (everglades_env.py:32-73, server.py:211-501).
 //
-// Mapping (DESIGN.md "Kernel design"): one env per LANE, one wavefront (64 envs) per workgroup.
-// The game rules are short, branchy integer programs with almost no intra-env parallelism
-// (7 ordered orders per player, ~1 contested node per turn), so a lane-per-env mapping executes
-// 64 envs per instruction, where a wave-per-env mapping would leave most lanes idle.  Everything
-// a lane indexes dynamically (its 24 group words, 11 node words, damage accumulators) lives in
-// LDS as [index][lane] columns: lane-private and bank-conflict-free by construction
-// (bank = lane mod 32, halves of the wave never collide).  The SoA state arrays are env-fastest,
-// so every state load/store is a fully coalesced 256-byte wave access; the observation block of
-// the wave's 64 envs (64 x 840 B, contiguous) is produced through an LDS transpose and written
-// with 16-byte-per-lane coalesced stores.  Constant map/unit tables are staged in LDS.
+// Mapping: lane = (env slot, player); one wavefront = 32 envs per workgroup.
+// The game rules are short, branchy integer programs with almost no parallelism inside one env
+// (7 orders per player, ~1 contested node per turn), so envs are spread over LANES: one instruction
+// serves 32 envs, where a wave-per-env mapping would leave most lanes idle.  Two lanes per env halve
+// every per-player loop and give 2 waves per SIMD at 65 536 envs (latency hiding); the pair exchanges
+// values with one DPP move.  Everything a lane indexes dynamically (its 12 group words, the node
+// words, per-node accumulators) lives in LDS as [index][lane] columns: lane-private and
+// bank-conflict-free by construction (bank = lane mod 32).  Combat is rebalanced over the whole wave:
+// a prefix scan over lanes builds one work item per fighting group, damage accumulates in a shared
+// LDS pool with integer LDS atomics (order-free, deterministic).  The SoA state arrays are
+// env-fastest (coalesced); the wave's observation block (32 x 840 B, contiguous in the output) is
+// assembled in LDS in output order and streamed out with 16-byte-per-lane coalesced stores.
+// Uniform map/unit tables sit in SGPRs as nibble-packed words, per-lane-indexed ones in LDS.
 // No MFMA: there is no dense contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 #include "evg_device.h"
@@ -34,25 +37,27 @@ namespace evg {
 #define STAMP(i)
 #endif
 
-constexpr int EPW = WG / 2;               // envs per wavefront: lane = 2 * env_slot + player
-constexpr int DP_CAP = 1536;              // words of the shared damage pool (worst case of 16 envs: 1056)
-
+// LPW = lanes of the wavefront that own an env side (lane = 2 * env_slot + player): 64 (32 envs per wave) or 32
+// (16 envs per wave; lanes 32..63 are helpers that only join the wave-balanced phases: combat items, write-out).
+template <int LPW>
 struct CombatLds {
-    uint32_t SNAP[12][WG];               // pre-combat snapshot of the lane's own group k:
+    static constexpr int DP_CAP = LPW == 64 ? 1536 : 768;   // words of the shared damage pool (worst case of LPW/2 lanes: 33 each)
+    uint32_t SNAP[12][LPW];              // pre-combat snapshot of the lane's own group k:
                                          //   bit31 fights | list-order prefix of alive units << 16 | node << 12 | alive mask
-    uint32_t FS[12][WG];                 // the lane's own side at node n: alive fighting units << 16 | word offset of its damage bytes in DP
-    uint32_t TURN[WG], EPI[WG];          // per-env scalars for lanes that work on another env's item
-    uint16_t W[WG * 12];                 // work list of fighting groups: owner lane | gid << 6
+    uint32_t FS[12][LPW];                // the lane's own side at node n: alive fighting units << 16 | word offset of its damage bytes in DP
+    uint32_t TURN[LPW], EPI[LPW];        // per-env scalars for lanes that work on another env's item
+    uint16_t W[LPW * 12];                // work list of fighting groups: owner lane | gid << 6
     uint32_t DP[DP_CAP];                 // damage pool: one byte per targeted unit index, filled with LDS atomics
 };
 
+template <int LPW>
 struct __align__(16) StepLds {
-    uint32_t G[12][WG];                  // group words, lane-private columns (lane = env slot, player)
-    uint32_t NW[12][EPW];                // node words by node ID, one column per env
+    uint32_t G[12][LPW];                 // group words, lane-private columns (lane = env slot, player)
+    uint32_t NW[12][LPW / 2];            // node words by node ID, one column per env
     union {                              // phases are disjoint in time (one wavefront per workgroup)
-        CombatLds c;
-        uint32_t A[12][WG];              // per (own side, node): capture points | units listed << 16
-        int16_t  O[WG * OBS];            // observations of the wave's 32 envs, already in output order [env][player][105]
+        CombatLds<LPW> c;
+        uint32_t A[12][LPW];             // per (own side, node): capture points | units listed << 16
+        int16_t  O[LPW * OBS];           // observations of the wave's envs, already in output order [env][player][105]
     } u;
     uint64_t adj[12];
     double   defense[12];
@@ -93,7 +98,6 @@ __device__ __forceinline__ void store_obs_vec<int16_t>(int16_t* dst, const int (
     *reinterpret_cast<uint4*>(dst) = o;
 }
 
-// value held by the other player's lane of the same env (lane ^ 1): one DPP quad_perm [1,0,3,2] move, no LDS round trip
 // random_actions stand-in for one (env, player): 7 distinct groups of 12 and 7 distinct nodes of 1..11
 // (agents/State_Machine/random_actions.py:38-46), partial Fisher-Yates on nibble-packed permutations.
 // Same contract as oracle/rng_spec.py random_action_rows.
@@ -122,19 +126,24 @@ __device__ __forceinline__ void gen_random_rows(const DevState& S, uint32_t env_
     for (int i = 0; i < NA; ++i) rows[i] = make_int2((int)((gp >> (4 * i)) & 15ull), (int)((np_ >> (4 * i)) & 15ull));
 }
 
+// value held by the other player's lane of the same env (lane ^ 1): one DPP quad_perm [1,0,3,2] move, no LDS round trip
 __device__ __forceinline__ int xchg1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 
 // ---------------------------------------------------------------------------------------------
-// fused env-step: lane = (env slot, player); 32 envs per wavefront
+// fused env-step: lane = (env slot, player); LPW / 2 envs per wavefront (LPW = 64 is the default variant)
 // ---------------------------------------------------------------------------------------------
-template <typename OT>
+template <typename OT, int LPW>
 __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
-    __shared__ StepLds L;
+    constexpr int EPW = LPW / 2;                        // envs per wavefront
+    constexpr int DP_CAP = CombatLds<LPW>::DP_CAP;
+    __shared__ StepLds<LPW> L;
     const int lane = threadIdx.x;
-    const int E = lane >> 1, P = lane & 1;
+    const bool envlane = LPW == WG || lane < LPW;       // owns an env side; helper lanes only join the balanced phases
+    const int E = envlane ? lane >> 1 : 0, P = lane & 1;
+    const int col = envlane ? lane : 0;                 // LDS column (helpers never write; their reads are discarded)
     const int e0 = blockIdx.x * EPW;
     const int nvalid = min(EPW, S.N - e0);
-    const bool valid = E < nvalid;
+    const bool valid = envlane && E < nvalid;
     const int e = valid ? e0 + E : e0;
     const size_t N = (size_t)S.N;
     const DevTables* __restrict__ T = S.T;
@@ -160,12 +169,14 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     uint32_t st[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) st[j] = S.stamp[(size_t)(P * 3 + j) * N + e];
+    if (envlane) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) L.G[k][lane] = S.grp[(size_t)(P * 12 + k) * N + e];
+        for (int k = 0; k < 12; ++k) L.G[k][lane] = S.grp[(size_t)(P * 12 + k) * N + e];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {                       // player 0 lane: nodes 1..6, player 1 lane: nodes 7..11
-        const int n = P ? 7 + j : 1 + j;
-        if (n <= NN) L.NW[n][E] = S.node[(size_t)(n - 1) * N + e];
+        for (int j = 0; j < 6; ++j) {                   // player 0 lane: nodes 1..6, player 1 lane: nodes 7..11
+            const int n = P ? 7 + j : 1 + j;
+            if (n <= NN) L.NW[n][E] = S.node[(size_t)(n - 1) * N + e];
+        }
     }
     // this player's 7 order rows: read from the caller's tensor (issued now, used after the barrier), or -- in the
     // fused random-vs-random rollout -- drawn here by the same generator as evg_random_actions and written out
@@ -234,7 +245,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     // along that order, so each fighting group gets the prefix `base` of alive units listed before it.
     uint32_t g[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) g[k] = L.G[k][lane];
+    for (int k = 0; k < 12; ++k) g[k] = envlane ? L.G[k][col] : 0u;
     uint32_t occ = 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -270,10 +281,9 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
             a1 += idx == 1 ? add : 0u;
             a2 += idx == 2 ? add : 0u;
             fmask |= (fights ? 1u : 0u) << gid;
-            L.u.c.SNAP[gid][lane] = fights ? (0x80000000u | (base << 16) | (loc << 12) | mask) : 0u;
+            if (envlane) L.u.c.SNAP[gid][lane] = fights ? (0x80000000u | (base << 16) | (loc << 12) | mask) : 0u;
         }
-        L.u.c.TURN[lane] = (uint32_t)turn;
-        L.u.c.EPI[lane] = episode;
+        if (envlane) { L.u.c.TURN[lane] = (uint32_t)turn; L.u.c.EPI[lane] = episode; }
         // damage bytes this side needs: one per alive fighting unit, rounded up to a word per node
         int ndw = 0;
         {
@@ -296,13 +306,13 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
             if (lane >= d) incl += t;
         }
         const int excl = incl - ((ndw << 16) | nfight);
-        const int tot = __shfl(incl, WG - 1), mid = __shfl(excl, WG / 2);
+        const int tot = __shfl(incl, WG - 1), mid = __shfl(excl, LPW / 2);
         const int excl_i = excl & 0xFFFF, excl_d = excl >> 16, tot_i = tot & 0xFFFF, tot_d = tot >> 16, mid_i = mid & 0xFFFF, mid_d = mid >> 16;
         // the pool holds every fight of the wave in the common case; otherwise two passes of 16 envs each
         const int npass = tot_d <= DP_CAP ? 1 : 2;
         const uint32_t dmg_nib = T->damage_nib, armor_byte = T->armor_byte;
         for (int ps = 0; ps < npass; ++ps) {
-            const bool inpass = npass == 1 || (lane >> 5) == ps;
+            const bool inpass = npass == 1 || (lane / (LPW / 2)) == ps;     // helper lanes own no items
             const int ref_i = (npass == 2 && ps == 1) ? mid_i : 0, ref_d = (npass == 2 && ps == 1) ? mid_d : 0;
             const int end_i = (npass == 2 && ps == 0) ? mid_i : tot_i, end_d = (npass == 2 && ps == 0) ? mid_d : tot_d;
             const int nitems = end_i - ref_i, ndwords = end_d - ref_d;
@@ -331,8 +341,9 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
 
             // health row of this lane's first item: issued now, consumed in phase B, so that the HBM latency hides
             // behind the draws (a fighting group is very likely to be hit; 64-96 B per group)
-            double hpre[12];
-            {
+            constexpr bool kPrefetch = LPW == WG;      // the 16-env variant runs at 4 waves/SIMD and has no registers to spare
+            double hpre[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (kPrefetch) {
                 const uint32_t item0 = L.u.c.W[lane < nitems ? lane : 0];
                 const int SL0 = (int)(item0 & 63u), gid0 = (int)(item0 >> 6);
                 const double2* r2 = reinterpret_cast<const double2*>(S.health + (size_t)(e0 + (SL0 >> 1)) * (2 * NU) + (SL0 & 1) * NU + gid0 * 8);
@@ -400,7 +411,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
                 if (any) {
                     double* row = S.health + (size_t)(e0 + (SL >> 1)) * (2 * NU) + side * NU + gid * 8;
                     double h[12];
-                    if (it < WG) {                                  // first round: prefetched before the draws
+                    if (kPrefetch && it < WG) {                     // first round: prefetched before the draws
 #pragma unroll
                         for (int sl = 0; sl < 12; ++sl) h[sl] = hpre[sl];
                     } else {
@@ -451,7 +462,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     // ---------------- movement of this lane's groups (server.py:656-706), branch-free
     uint32_t gw[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) gw[k] = L.G[k][lane];
+    for (int k = 0; k < 12; ++k) gw[k] = envlane ? L.G[k][col] : 0u;
     if (play && !(abl & 4u)) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
@@ -474,8 +485,10 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     STAMP(7);
 
     // ---------------- per-node aggregates of this side (post-movement): capture points | units listed << 16
+    if (envlane) {
 #pragma unroll
-    for (int n = 0; n < 12; ++n) L.u.A[n][lane] = 0;
+        for (int n = 0; n < 12; ++n) L.u.A[n][lane] = 0;
+    }
     int my_unit_score = 0, my_alive = 0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -484,7 +497,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         const bool elig = ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;                          // :720
         const uint32_t ctl = (uint32_t)((ctl_n >> (4 * k)) & 15u);
         const uint32_t add = (elig ? (uint32_t)cnt * ctl : 0u) | ((uint32_t)cnt << 16);
-        atomicAdd(&L.u.A[w & G_LOC_M][lane], add);                                              // ds_add_u32 (adds 0 for a destroyed group)
+        if (envlane) atomicAdd(&L.u.A[w & G_LOC_M][lane], add);                                 // ds_add_u32 (adds 0 for a destroyed group)
         my_unit_score += cnt * (int)((cst_n >> (4 * k)) & 15u);                                 // :315-317
         my_alive += cnt;
     }
@@ -499,8 +512,8 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {                  // all LDS / table reads first, then pure ALU
             const int n = (P ? 7 + j : 1 + j) % 12;    // j = 5 of player 1 is the unused slot 0
-            a0v[j] = L.u.A[n][lane & ~1];
-            a1v[j] = L.u.A[n][lane | 1];
+            a0v[j] = L.u.A[n][col & ~1];
+            a1v[j] = L.u.A[n][col | 1];
             nwv[j] = L.NW[n][E];
             cpv[j] = P ? T->control_points[(7 + j) % 12] : T->control_points[1 + j];
             tsv[j] = P ? T->team_start[(7 + j) % 12] : T->team_start[1 + j];
@@ -615,11 +628,13 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     for (int i = 1; i <= NN; ++i) {
         const int n = P ? (int)((p1nib >> (4 * i)) & 15u) : i;                    // slot i of player 1 shows node p1_node_map[i] (:437-439)
         cs_s[i] = (int)(L.NW[n][E] & 0x3FFu) - 512;                               // control sign not mirrored
-        ou_s[i] = (int)(L.u.A[n][lane ^ 1] >> 16);                                // opposing units listed at the node, moving ones included
+        ou_s[i] = (int)(L.u.A[n][col ^ 1] >> 16);                                // opposing units listed at the node, moving ones included
     }
     __syncthreads();        // A is dead from here on: the union becomes the output image
-    int16_t* orow = &L.u.O[lane * OBS];
-    if (do_reset) {
+    int16_t* orow = &L.u.O[col * OBS];
+    if (!envlane) {
+        // helper lane: nothing to write
+    } else if (do_reset) {
 #pragma unroll
         for (int i = 0; i < OBS; ++i) orow[i] = P ? T->reset_obs[OBS + i] : T->reset_obs[i];
     } else {
@@ -670,7 +685,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     // converts 16 bytes' worth per iteration (conflict-free LDS reads, fully coalesced 1 KiB stores per wave)
     if (io.obs && !(abl & 16u)) {
         constexpr int EP = 16 / (int)sizeof(OT);          // elements per 16-byte vector
-        constexpr int NVEC = WG * OBS / EP;
+        constexpr int NVEC = LPW * OBS / EP;
         const int limit = nvalid * OBS2;
         OT* out = reinterpret_cast<OT*>(io.obs) + (size_t)e0 * OBS2;
 #pragma unroll 4
@@ -702,7 +717,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     STAMP(12);
 
     // ---------------- health of envs that start a new episode: 1600 B each, written by the whole wave
-    uint64_t rm = __ballot(do_reset && P == 0);
+    uint64_t rm = __ballot(do_reset && P == 0);        // do_reset is false on helper lanes
     while (rm) {
         const int l = __ffsll((unsigned long long)rm) - 1;
         rm &= rm - 1;
@@ -870,13 +885,24 @@ __global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* out) 
 // launchers
 // ---------------------------------------------------------------------------------------------
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
-    const dim3 grid((S.N + EPW - 1) / EPW), block(WG);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    switch (obs_dtype) {
-        case EVG_OBS_F32: hipLaunchKernelGGL(evg_step_kernel<float>, grid, block, 0, s, S, io); break;
-        case EVG_OBS_F64: hipLaunchKernelGGL(evg_step_kernel<double>, grid, block, 0, s, S, io); break;
-        case EVG_OBS_I16: hipLaunchKernelGGL(evg_step_kernel<int16_t>, grid, block, 0, s, S, io); break;
-        default: return -1;
+    const dim3 block(WG);
+    if (io.lanes_per_wave == 32) {
+        const dim3 grid((S.N + 15) / 16);
+        switch (obs_dtype) {
+            case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, 32>), grid, block, 0, s, S, io); break;
+            case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, 32>), grid, block, 0, s, S, io); break;
+            case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, 32>), grid, block, 0, s, S, io); break;
+            default: return -1;
+        }
+    } else {
+        const dim3 grid((S.N + 31) / 32);
+        switch (obs_dtype) {
+            case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, 64>), grid, block, 0, s, S, io); break;
+            case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, 64>), grid, block, 0, s, S, io); break;
+            case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, 64>), grid, block, 0, s, S, io); break;
+            default: return -1;
+        }
     }
     return (int)hipGetLastError();
 }

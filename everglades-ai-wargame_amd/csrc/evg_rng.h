@@ -14,8 +14,9 @@ constexpr int RNG_COMBAT = 0, RNG_ACTION = 1, RNG_SWARM = 2;
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(PHILOX_M0, c.x), lo0 = PHILOX_M0 * c.x;
-        const uint32_t hi1 = __umulhi(PHILOX_M1, c.z), lo1 = PHILOX_M1 * c.z;
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a v_mul_hi_u32 / v_mul_lo_u32 pair
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * (uint64_t)c.x, p1 = (uint64_t)PHILOX_M1 * (uint64_t)c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
         k0 += PHILOX_W0;
         k1 += PHILOX_W1;
