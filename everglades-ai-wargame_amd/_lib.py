@@ -13,7 +13,10 @@ NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11,
 MAX_SCORE = 3700
 OBS_F32, OBS_F64, OBS_I16 = 0, 1, 2
 ABI_VERSION = 1
-POLICY_RANDOM, POLICY_CYCLE_RUSH_25, POLICY_CYCLE_RUSH_50, POLICY_SWARM = 0, 1, 2, 3
+POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "all_cycle", "base_rush_v1", "bull_rush",
+                "cycle_target_node", "cycle_target_node1", "cycle_target_node11", "cycle_target_node11P2", "dfs_attack", "no_action",
+                "random_actions_delay", "same_commands"]      # index = EVG_POLICY_* of include/evg.h (agents/State_Machine/<name>.py)
+POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
 EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_fog_of_war", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
            "evg_get_state", "evg_set_state", "evg_episode_stats", "evg_episode_stats_device", "evg_num_envs",

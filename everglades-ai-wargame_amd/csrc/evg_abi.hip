@@ -99,6 +99,51 @@ void evg_default_tables(evg_tables* t) {
     t->max_turns = 150;
 }
 
+// dfs_attack.py ignores its observation, so its orders are a function of the call count alone.  Simulate the bot
+// (depth-first sweep over the map with two attack groups, delays in between, and the rows that persist in the mutable
+// default argument of act_dfs_attack) until its whole state repeats; the kernel then indexes the table.
+static void build_dfs_table(const evg_tables& t, DevTables* D) {
+    struct St { int first, group_index, delay_turns, delay, prev; uint32_t visited; std::vector<int> stack; uint64_t persist;
+                bool operator==(const St& o) const { return first == o.first && group_index == o.group_index && delay_turns == o.delay_turns &&
+                    delay == o.delay && prev == o.prev && visited == o.visited && stack == o.stack && persist == o.persist; } };
+    St s{1, 0, 5, 0, 1, 0u, {1}, 0ull};
+    std::vector<St> seen;
+    std::vector<uint64_t> rows;
+    auto set_row = [](uint64_t& p, int i, int g, int n) { p = (p & ~(0xFFull << (8 * i))) | ((uint64_t)(g | (n << 4)) << (8 * i)); };
+    for (int call = 0; call < 192; ++call) {
+        int hit = -1;
+        for (size_t k = 0; k < seen.size(); ++k) if (seen[k] == s) { hit = (int)k; break; }
+        if (hit >= 0) { D->dfs_mu = hit; D->dfs_lambda = call - hit; break; }
+        seen.push_back(s);
+        uint64_t out = 0;                                          // np.zeros(shape)
+        if (s.first) { s.first = 0; }
+        else if (s.group_index == 2 || s.delay) {
+            s.group_index = 0;
+            if (s.delay_turns == 0) { s.delay_turns = 10; s.delay = 0; } else { s.delay = 1; s.delay_turns -= 1; }
+        } else {
+            const bool all = s.visited == 0x7FFu;
+            if (s.group_index == 1) {
+                for (int i = 0; i < 5; ++i) set_row(s.persist, i, 7 + i, s.prev);
+                s.group_index += 1;
+            } else if (s.group_index == 0 && !all) {
+                const int n = s.stack.back();
+                s.prev = n;
+                for (int i = 0; i < NA; ++i) set_row(s.persist, i, i, n);
+                s.group_index += 1;
+                s.stack.pop_back();
+                s.visited |= 1u << (n - 1);
+                for (int m = 1; m <= NN; ++m) if (t.node_dist[n][m] > 0 && !((s.visited >> (m - 1)) & 1u)) s.stack.push_back(m);
+            } else {
+                s.group_index = 0; s.delay_turns = 5; s.delay = 0; s.stack.assign(1, 1); s.visited = 0u;
+            }
+            out = s.persist;
+        }
+        rows.push_back(out);
+    }
+    if (D->dfs_lambda <= 0) { D->dfs_mu = 0; D->dfs_lambda = (int)rows.size(); }     // not reached for connected maps
+    for (size_t k = 0; k < rows.size() && k < 192; ++k) D->dfs_rows[k] = rows[k];
+}
+
 static int build_dev_tables(const evg_config* cfg, DevTables* D) {
     const evg_tables& t = cfg->tables;
     memset(D, 0, sizeof(*D));
@@ -173,6 +218,13 @@ static int build_dev_tables(const evg_config* cfg, DevTables* D) {
             D->cost_nib[p] |= (uint64_t)t.unit_cost[ty] << (4 * g);
         }
     for (int i = 1; i <= NN; ++i) D->p1inv_nib |= (uint64_t)i << (4 * t.p1_node_map[i]);
+    // routing rows of cycle_target_node*.py (TAR_NODE[1], TAR_NODE[11]); 15 stands for the bots' -1 at the target itself
+    static const int to1[11] = {-1, 1, 4, 1, 2, 3, 4, 5, 7, 7, 8}, to11[11] = {2, 5, 7, 7, 8, 9, 10, 11, 10, 11, -1};
+    for (int c = 1; c <= NN; ++c) {
+        D->tar_to_1 |= (uint64_t)(to1[c - 1] < 0 ? 15 : to1[c - 1]) << (4 * c);
+        D->tar_to_11 |= (uint64_t)(to11[c - 1] < 0 ? 15 : to11[c - 1]) << (4 * c);
+    }
+    build_dfs_table(t, D);
     for (int n = 1; n <= NN; ++n) {
         int best = 0;
         for (int m = 1; m <= NN; ++m) if (t.node_dist[n][m] > 0) best = m;
@@ -245,6 +297,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (!rc) rc = dev_alloc(h, &S.totals, 4);
     if (!rc) rc = dev_alloc(h, &S.agent_cycle, 2 * N);
     if (!rc) rc = dev_alloc(h, &S.agent_swarm, 2 * N);
+    if (!rc) rc = dev_alloc(h, &S.agent_dfs, 2 * N);
     if (!rc) rc = dev_alloc(h, &h->d_tables, 1);
     if (rc) { evg_destroy(h); return rc; }
     S.T = h->d_tables;
@@ -323,7 +376,7 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
 
 int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream) {
     if (!h || !obs || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
-    if (policy < EVG_POLICY_RANDOM || policy > EVG_POLICY_SWARM || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "policy/player out of range");
+    if (policy < 0 || policy >= EVG_POLICY_COUNT || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "policy/player out of range");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     const int rc = launch_scripted_actions(h->S, policy, player, obs, actions_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "scripted_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -357,7 +410,7 @@ int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf
 
 int evg_rollout_policies(evg_handle* h, int steps, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
                          uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
-    if (policy0 < EVG_POLICY_RANDOM || policy0 > EVG_POLICY_SWARM || policy1 < EVG_POLICY_RANDOM || policy1 > EVG_POLICY_SWARM)
+    if (policy0 < 0 || policy0 >= EVG_POLICY_COUNT || policy1 < 0 || policy1 >= EVG_POLICY_COUNT)
         return fail(EVG_ERR_INVALID, "policy out of range");
     if (!obs_out) return fail(EVG_ERR_INVALID, "rollout_policies: obs_out is required (the agents read it)");
     return rollout_impl(h, steps, 0, policy0, policy1, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out,

@@ -43,6 +43,9 @@ struct DevTables {
     uint64_t p1map_nib;          // nibble i = p1_node_map[i]
     uint64_t type_nib[2];        // nibble k = unit type of group k
     uint64_t speed_nib[2], control_nib[2], cost_nib[2];   // nibble k = speed / control / cost of group k's unit type
+    uint64_t tar_to_1, tar_to_11;   // cycle_target_node*.py routing rows: nibble c = next hop from node c towards node 1 / 11 (15 = the bots' -1)
+    int32_t  dfs_mu, dfs_lambda;    // dfs_attack.py order sequence: transient length and period
+    uint64_t dfs_rows[192];         // row r, byte i = (group | node << 4) of order i
     uint32_t nbr_mask[12];       // bit m of entry n: node m is connected to node n
     uint64_t maxnbr_nib;         // nibble n = highest-numbered neighbour of node n (SwarmAgent's next hop)
     uint64_t p1inv_nib;          // nibble n = slot of p1's board view that shows node n (inverse of p1_node_map)
@@ -72,6 +75,7 @@ struct DevState {
     unsigned long long* totals;
     uint32_t* agent_cycle;       // [2][N] scripted-agent state: first_turn << 8 | group_num << 4 | node_num
     uint32_t* agent_swarm;       // [2][N] SwarmAgent attack list, 8 nibbles
+    uint32_t* agent_dfs;         // [2][N] dfs_attack call counter
     uint32_t  seed_lo, seed_hi, env_id_base;
     const DevTables* T;
 };

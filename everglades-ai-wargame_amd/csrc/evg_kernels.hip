@@ -205,18 +205,23 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         turn += 1;                                                               // server.py:214
         // ---------------- orders of this lane's player (server.py:218-271)
         // Accepting an order changes neither the group's location nor whether it is `moving`, so tests 2 and 3
-        // of every row can be taken from the pre-order words; rows interact only through test 1 (a group already
-        // commanded this turn).  That makes the 7 LDS lookups independent instead of a 7-deep dependent chain.
+        // of every row can be taken from the pre-order words; rows interact only through test 1 (an id already
+        // commanded this turn) and, for aliased ids, through the order of the writes (the later row wins, as in
+        // the reference).  That makes the 7 LDS lookups independent instead of a 7-deep dependent chain.
         if (!(abl & 1u)) {
-            int gidv[NA], nidv[NA];
+            int gidv[NA], nidv[NA], rawv[NA];
             uint32_t wv[NA], dv[NA];
             bool okv[NA];
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 int gid = act[i].x, nid = act[i].y;
-                okv[i] = (uint32_t)gid < 12u && (uint32_t)nid < 12u;            // build-defined domain
-                gid = okv[i] ? gid : 0;
-                nid = okv[i] ? nid : 0;
+                // Domain: ids in [-12, 11] behave like the reference's Python lists (a negative index counts from the end:
+                // groups[gid] at :235, p1_node_map[nid] at :92 for player 1); for player 0 a negative node id matches no
+                // connection; anything else would raise in the reference and is an invalid order here.
+                okv[i] = gid >= -12 && gid < 12 && nid >= (P ? -12 : 0) && nid < 12;
+                rawv[i] = okv[i] ? gid + 12 : 0;                                 // used_swarms keeps the ids as given (:241,252)
+                gid = okv[i] ? (gid < 0 ? gid + 12 : gid) : 0;
+                nid = okv[i] ? (nid < 0 ? nid + 12 : nid) : 0;
                 nidv[i] = P ? (int)((p1nib >> (4 * nid)) & 15u) : nid;           // :233-234
                 gidv[i] = gid;
                 wv[i] = L.G[gid][lane];
@@ -228,8 +233,8 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const uint32_t w = wv[i];
-                const bool accept = okv[i] && !((used >> gidv[i]) & 1u) && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING && dv[i] != 0;
-                used |= (accept ? 1u : 0u) << gidv[i];
+                const bool accept = okv[i] && !((used >> rawv[i]) & 1u) && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING && dv[i] != 0;
+                used |= (accept ? 1u : 0u) << rawv[i];
                 if (accept)                                                      // :267-270
                     L.G[gidv[i]][lane] = (w & ~(G_DEST_M | G_DIST_M | G_MODE_M)) | ((uint32_t)nidv[i] << G_DEST_S) | (dv[i] << G_DIST_S) |
                                          (MODE_READY << G_MODE_S);
@@ -789,48 +794,112 @@ __global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int
 //                                 module-global attack list -> keyed Fisher-Yates (oracle/rng_spec.py swarm_shuffle)
 // One thread per env; reads the player's observation row (turn, group locations, moving flags).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cycle_advance(int& group_num, int& node_num) {
+    group_num = (group_num + 1) % NG;
+    if (group_num == 0) node_num = node_num % NN + 1;
+}
+
 template <typename OT>
 __global__ void __launch_bounds__(256) evg_scripted_actions_kernel(DevState S, int policy, int player, const OT* obs, int32_t* actions) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= S.N) return;
+    const DevTables* __restrict__ T = S.T;
     const OT* o = obs + ((size_t)e * 2 + player) * OBS;
     int2* out = reinterpret_cast<int2*>(actions) + ((size_t)e * 2 + player) * NA;
+    const size_t ai = (size_t)player * S.N + e;
     const int turn = (int)o[0];
+    const uint32_t env_id = S.env_id_base + (uint32_t)e;
     int2 rows[NA];
-    if (policy == EVG_POLICY_RANDOM) {
-        gen_random_rows(S, S.env_id_base + (uint32_t)e, S.episode[e], turn, player, rows);
-    } else if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 0);                   // np.zeros(shape)
+    // cycling state shared by most bots: first_turn << 8 | group_num << 4 | node_num | strat_index << 9 | agentNumber==2 << 13
+    uint32_t cst = S.agent_cycle[ai];
+    int first = (int)((cst >> 8) & 1u), group_num = (int)((cst >> 4) & 15u), node_num = (int)(cst & 15u);
+    int strat = (int)((cst >> 9) & 15u), agent2 = (int)((cst >> 13) & 1u);
+    bool cyc_dirty = false;
+
+    if (policy == EVG_POLICY_RANDOM || policy == EVG_POLICY_RANDOM_DELAY) {
+        // random_actions.py:38-46, random_actions_2.py; random_actions_delay.py acts only when random.random() > 0.68
+        bool go = true;
+        if (policy == EVG_POLICY_RANDOM_DELAY) {
+            const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id, S.episode[e], RNG_DELAY, 0u, turn, 0, player, 0);
+            go = (double)x.x / 4294967296.0 > 0.68;
+        }
+        if (go) gen_random_rows(S, env_id, S.episode[e], turn, player, rows);
+    } else if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50 || policy == EVG_POLICY_BASE_RUSH_V1 ||
+               policy == EVG_POLICY_ALL_CYCLE) {
+        // cycle_rush_turn25.py:62-115 (gate 25 / 50), base_rush_v1.py:62-96 (row i only while group i is not at node 11),
+        // all_cycle.py (always)
         const int gate = policy == EVG_POLICY_CYCLE_RUSH_25 ? 25 : 50;
-        uint32_t st = S.agent_cycle[(size_t)player * S.N + e];     // bit 8 first_turn | group_num << 4 | node_num
-        int first = (int)((st >> 8) & 1u), group_num = (int)((st >> 4) & 15u), node_num = (int)(st & 15u);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int loc_i = (int)o[45 + 5 * i];
-            const bool issue = !first && ((loc_i != 11 && turn > gate) || turn < gate);   // :92 (Python precedence)
-            rows[i] = issue ? make_int2(group_num, node_num) : make_int2(0, 0);
-            if (issue) {
-                group_num = (group_num + 1) % NG;
-                if (group_num == 0) node_num = node_num % NN + 1;
+            bool issue = !first;
+            if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50) issue = issue && ((loc_i != 11 && turn > gate) || turn < gate);
+            if (policy == EVG_POLICY_BASE_RUSH_V1) issue = issue && loc_i != 11;
+            if (issue) { rows[i] = make_int2(group_num, node_num); cycle_advance(group_num, node_num); }
+        }
+        first = 0; cyc_dirty = true;
+    } else if (policy == EVG_POLICY_BULL_RUSH) {                           // bull_rush.py: all groups to 2, 2, 5, 5, 8, 8, 11, 11, ...
+        if (!first) {
+            if (strat == 8) strat = 0;
+            const int node = (int)((0xB852u >> (4 * (strat >> 1))) & 15u);   // node_strat = [2, 5, 8, 11]
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { rows[i] = make_int2(group_num, node); group_num = (group_num + 1) % NG; }
+            strat += 1;
+        }
+        first = 0; cyc_dirty = true;
+    } else if (policy >= EVG_POLICY_CYCLE_TARGET_NODE && policy <= EVG_POLICY_CYCLE_TARGET_NODE11P2) {
+        // cycle_target_node.py (target 11, level 75), ..._node1.py (1, 75), ..._node11.py (11, 500), ..._node11P2.py (11, +-500)
+        const int tar = policy == EVG_POLICY_CYCLE_TARGET_NODE1 ? 1 : 11, level = policy >= EVG_POLICY_CYCLE_TARGET_NODE11 ? 500 : 75;
+        if (first) {
+            if (policy == EVG_POLICY_CYCLE_TARGET_NODE11P2 && (int)o[44] > 0) agent2 = 1;
+        } else {
+            const int ctl = (int)o[tar * 4 - 1];
+            const bool controlled = (policy == EVG_POLICY_CYCLE_TARGET_NODE11P2 && agent2) ? ctl <= -level : ctl >= level;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (controlled) {
+                    rows[i] = make_int2(group_num, node_num);
+                    cycle_advance(group_num, node_num);
+                } else {
+                    const int cur = (int)o[45 + 5 * group_num];
+                    const int nx = (int)(((tar == 1 ? T->tar_to_1 : T->tar_to_11) >> (4 * cur)) & 15ull);   // 15 encodes the bots' -1
+                    rows[i] = make_int2(group_num, nx == 15 ? -1 : nx);
+                    group_num = (group_num + 1) % NG;
+                }
             }
         }
-        S.agent_cycle[(size_t)player * S.N + e] = (uint32_t)node_num | ((uint32_t)group_num << 4);   // first_turn cleared, :73-76
-    } else {                                                       // EVG_POLICY_SWARM
-        uint32_t lst = S.agent_swarm[(size_t)player * S.N + e];    // attack list, 8 nibbles
-        const uint32_t env_id = S.env_id_base + (uint32_t)e, episode = S.episode[e];
+        first = 0; cyc_dirty = true;
+    } else if (policy == EVG_POLICY_DFS_ATTACK) {
+        // dfs_attack.py ignores the observation: its orders are an eventually periodic sequence of the call count,
+        // tabulated on the host at evg_create (including the rows that persist in its mutable default argument)
+        const uint32_t c = S.agent_dfs[ai];
+        const uint32_t idx = c < (uint32_t)T->dfs_mu ? c : (uint32_t)T->dfs_mu + (c - (uint32_t)T->dfs_mu) % (uint32_t)T->dfs_lambda;
+        const uint64_t r = T->dfs_rows[idx];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rows[i] = make_int2((int)((r >> (8 * i)) & 15ull), (int)((r >> (8 * i + 4)) & 15ull));
+        S.agent_dfs[ai] = c + 1u;
+    } else if (policy == EVG_POLICY_SAME_COMMANDS) {                        // same_commands.py / same_commands_2.py
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rows[i] = make_int2(i + 1, i + 1);
+    } else if (policy == EVG_POLICY_SWARM) {
+        uint32_t lst = S.agent_swarm[ai];                                  // attack list, 8 nibbles
+        const uint32_t episode = S.episode[e];
         const uint4 x0 = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_SWARM, 0u, turn, 0, player, 0);
         const uint4 x1 = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_SWARM, 1u, turn, 0, player, 0);
         const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {                              // i = 7 .. 1
+        for (int k = 0; k < 7; ++k) {                                      // i = 7 .. 1
             const int i = 7 - k;
             const int j = (int)__umulhi(w[k], (uint32_t)(i + 1));
             const uint32_t x = ((lst >> (4 * i)) ^ (lst >> (4 * j))) & 15u;
             lst ^= (x << (4 * i)) ^ (x << (4 * j));
         }
-        S.agent_swarm[(size_t)player * S.N + e] = lst;
+        S.agent_swarm[ai] = lst;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 1);    // np.tile([0, 1], (7, 1))
-        const uint64_t mx = S.T->maxnbr_nib;
+        for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 1);            // np.tile([0, 1], (7, 1))
+        const uint64_t mx = T->maxnbr_nib;
         int n = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -842,7 +911,9 @@ __global__ void __launch_bounds__(256) evg_scripted_actions_kernel(DevState S, i
             for (int i = 0; i < NA; ++i) rows[i] = (idle && n == i) ? r : rows[i];
             n += (idle && n < NA) ? 1 : 0;
         }
-    }
+    }                                                                      // EVG_POLICY_NO_ACTION: zeros
+    if (cyc_dirty)
+        S.agent_cycle[ai] = (uint32_t)node_num | ((uint32_t)group_num << 4) | ((uint32_t)first << 8) | ((uint32_t)strat << 9) | ((uint32_t)agent2 << 13);
 #pragma unroll
     for (int i = 0; i < NA; ++i) out[i] = rows[i];
 }
@@ -852,6 +923,7 @@ __global__ void evg_scripted_reset_kernel(DevState S) {
     if (i >= 2 * S.N) return;
     S.agent_cycle[i] = 0x112u;             // first_turn = 1, group_num = 1, node_num = 2 (cycle_rush_turn25.py:49,56-57)
     S.agent_swarm[i] = 0xBA875421u;        // ATTACK_LIST = [1,2,4,5,7,8,10,11] (swarm_agent.py:29), nibble k = entry k
+    S.agent_dfs[i] = 0u;                   // dfs_attack call counter
 }
 
 // ---------------------------------------------------------------------------------------------

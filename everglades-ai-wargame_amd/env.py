@@ -43,13 +43,14 @@ def _make_spaces(env):
 def canonical_actions(action):
     """What the server does with a player's array before using it: it must have 2 columns, only the
     first 7 rows count, values are truncated to int (server.py:225-232).  Missing rows become the
-    always-invalid order (0, 0)."""
+    always-invalid order (0, 0).  Ids in [-12, 11] pass through (negative ones index from the end like the
+    reference's Python lists); anything else, which would raise IndexError there, becomes an invalid order."""
     a = np.asarray(action)
     if a.ndim != 2 or a.shape[1] != 2:
         raise AssertionError("Did not receive 2 columns for a player's action")
     a = a[:7].astype(int)
     out = np.zeros((7, 2), np.int32)
-    out[:len(a)] = np.clip(a, -1, 12)       # anything outside [0, 11] is an invalid order
+    out[:len(a)] = np.where((a >= -12) & (a <= 11), a, 99)
     return out
 
 

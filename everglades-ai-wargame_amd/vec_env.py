@@ -156,11 +156,11 @@ class EvergladesVecEnv(object):
         _lib.check(self.L.evg_random_actions(self._h, self._ptr(out), self._stream()))
         return out
 
-    POLICIES = {"random": _lib.POLICY_RANDOM, "cycle_rush_turn25": _lib.POLICY_CYCLE_RUSH_25,
-                "cycle_rush_turn50": _lib.POLICY_CYCLE_RUSH_50, "swarm": _lib.POLICY_SWARM}
+    POLICIES = dict({n: i for i, n in enumerate(_lib.POLICY_NAMES)}, **_lib.POLICY_ALIASES)
 
     def scripted_actions(self, policy, player, obs=None, out=None):
-        """Orders of the on-device scripted agent `policy` ("random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm")
+        """Orders of the on-device scripted agent `policy` (a name from _lib.POLICY_NAMES = the file names under
+        agents/State_Machine/, or an EVG_POLICY_* id)
         playing seat `player` in every env, from the observations `obs` (default: the env's own obs buffer).  Writes
         rows [:, player] of `out` (default: the env's action buffer) and returns it.  Agent objects persist across
         episodes like the reference's; scripted_reset() re-creates them."""

@@ -120,8 +120,10 @@ int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream);
  * (server.py:211-279: orders, combat :503, movement :656, capture :708, game_end :281) ->
  * board_state/player_state (:382-501).  build_knowledge_output (:769-907) mutates nothing and is
  * not reproduced.
- *   actions    device int32 [N][2][7][2]  (group id, node id in the player's own numbering);
- *              out-of-domain ids are invalid orders, never undefined behaviour
+ *   actions    device int32 [N][2][7][2]  (group id, node id in the player's own numbering); ids in [-12, -1]
+ *              index from the end like the reference's Python lists (group -1 is group 11; for player 1 node -1
+ *              is p1_node_map[-1]; `used_swarms` dedupes on the id as given); any other out-of-range id is an
+ *              invalid order, never undefined behaviour
  *   obs_out    device [N][2][105] of cfg.obs_dtype
  *   reward_out device float [N][2]   (everglades_env.py:37-61)
  *   done_out   device uint8 [N]
@@ -152,11 +154,29 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream);
  * and alive across episodes like the reference's (evaluate.py:85-93).  Reads `player`'s rows of obs (device
  * [N][2][105] of cfg.obs_dtype, as written by evg_step/evg_reset) and writes that player's 7 order rows of
  * actions_out (device int32 [N][2][7][2]).
- *   EVG_POLICY_RANDOM          random_actions.py:38-46 (same generator as evg_random_actions)
- *   EVG_POLICY_CYCLE_RUSH_25   cycle_rush_turn25.py:62-115        EVG_POLICY_CYCLE_RUSH_50  cycle_rush_turn50.py
- *   EVG_POLICY_SWARM           swarm_agent.py:66-102 (its list shuffle keyed like every other draw)
+ * All 17 bots of agents/State_Machine/ are covered by the 15 ids below (two pairs of files are identical in
+ * behaviour); their random draws (np.random.choice, np.random.shuffle, random.random) are keyed like every other
+ * draw.  Order ids a bot emits outside [0, 11] (e.g. the -1 of cycle_target_node*.py) are passed
+ * through; evg_step treats them like the reference's Python lists do.
  * evg_scripted_reset re-creates all agent objects (first_turn, cycling position, attack list). */
-enum { EVG_POLICY_RANDOM = 0, EVG_POLICY_CYCLE_RUSH_25 = 1, EVG_POLICY_CYCLE_RUSH_50 = 2, EVG_POLICY_SWARM = 3 };
+enum {
+    EVG_POLICY_RANDOM = 0,                 /* random_actions.py, random_actions_2.py                         */
+    EVG_POLICY_CYCLE_RUSH_25 = 1,          /* cycle_rush_turn25.py                                           */
+    EVG_POLICY_CYCLE_RUSH_50 = 2,          /* cycle_rush_turn50.py                                           */
+    EVG_POLICY_SWARM = 3,                  /* swarm_agent.py                                                 */
+    EVG_POLICY_ALL_CYCLE = 4,              /* all_cycle.py                                                   */
+    EVG_POLICY_BASE_RUSH_V1 = 5,           /* base_rush_v1.py                                                */
+    EVG_POLICY_BULL_RUSH = 6,              /* bull_rush.py                                                   */
+    EVG_POLICY_CYCLE_TARGET_NODE = 7,      /* cycle_target_node.py   (target 11, level 75)                   */
+    EVG_POLICY_CYCLE_TARGET_NODE1 = 8,     /* cycle_target_node1.py  (target 1, level 75)                    */
+    EVG_POLICY_CYCLE_TARGET_NODE11 = 9,    /* cycle_target_node11.py (target 11, level 500)                  */
+    EVG_POLICY_CYCLE_TARGET_NODE11P2 = 10, /* cycle_target_node11P2.py                                       */
+    EVG_POLICY_DFS_ATTACK = 11,            /* dfs_attack.py                                                  */
+    EVG_POLICY_NO_ACTION = 12,             /* no_action.py                                                   */
+    EVG_POLICY_RANDOM_DELAY = 13,          /* random_actions_delay.py                                        */
+    EVG_POLICY_SAME_COMMANDS = 14,         /* same_commands.py, same_commands_2.py                           */
+    EVG_POLICY_COUNT = 15
+};
 int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream);
 int evg_scripted_reset(evg_handle* h, void* stream);
 

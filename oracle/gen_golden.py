@@ -248,12 +248,12 @@ def pol_wild(ctx, p, obs):
     r = ctx["nprng"]
     rows = int(r.integers(5, 10))
     a = np.zeros((rows, 2))
-    a[:, 0] = r.integers(0, 12, rows)
-    a[:, 1] = r.integers(0, 12, rows)
+    a[:, 0] = r.integers(-12, 12, rows)      # negative ids index from the end in the reference's Python lists
+    a[:, 1] = r.integers(-12, 12, rows)
     if r.random() < 0.5:  # duplicate group ids
         a[r.integers(0, rows), 0] = a[0, 0]
     frac = r.random((rows, 2)) * 0.999
-    a = a + frac * (r.random((rows, 2)) < 0.3)  # fractional floats truncate (server.py:232)
+    a = a + np.sign(a + 0.5) * frac * (r.random((rows, 2)) < 0.3)  # fractional floats truncate toward zero (server.py:232)
     return a
 
 
@@ -386,7 +386,8 @@ def pack(games, metas, tmax=150):
 # scripted agents of BASELINE config 5, loaded from the reference by file path (they import only numpy)
 # ----------------------------------------------------------------------------------------------
 class _AgentRandomProxy(object):
-    """np.random for swarm_agent.py: shuffle(list) becomes the keyed Fisher-Yates of rng_spec.swarm_shuffle."""
+    """np.random for the scripted agents: shuffle(list) (swarm_agent.py) becomes the keyed Fisher-Yates of
+    rng_spec.swarm_shuffle; choice(., 7, replace=False) (random_actions*.py) the columns of rng_spec.random_action_rows."""
 
     def __init__(self, owner):
         self._o = owner
@@ -395,6 +396,26 @@ class _AgentRandomProxy(object):
         L = sys._getframe(1).f_locals
         o = self._o
         lst[:] = rng_spec.swarm_shuffle(o.seed, o.env_id, o.episode, int(L["obs"][0]), L["self"]._evg_player, lst)
+
+    def choice(self, a, size, replace=True):
+        L = sys._getframe(1).f_locals
+        o = self._o
+        rows = rng_spec.random_action_rows(o.seed, o.env_id, o.episode, int(L["obs"][0]), L["self"]._evg_player)
+        n = a if isinstance(a, int) else len(a)
+        assert size == 7 and not replace and n in (11, 12)
+        return np.array([r[0] for r in rows]) if n == 12 else np.array([r[1] for r in rows])     # 12: groups, 11: node ids 1..11
+
+
+class _StdRandomProxy(object):
+    """The stdlib `random` module inside random_actions_delay.py: random() becomes rng_spec.delay_uniform."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def random(self):
+        L = sys._getframe(1).f_locals
+        o = self._o
+        return rng_spec.delay_uniform(o.seed, o.env_id, o.episode, int(L["obs"][0]), L["self"]._evg_player)
 
     def __getattr__(self, k):
         return getattr(np.random, k)
@@ -420,12 +441,25 @@ def load_agent(proxy, filename, classname, player):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.np = _AgentNpProxy(proxy)
-    agent = getattr(mod, classname)(NA, player)
+    if hasattr(mod, "random"):
+        mod.random = _StdRandomProxy(proxy)
+    cls = getattr(mod, classname)
+    import inspect
+    nargs = len(inspect.signature(cls.__init__).parameters) - 1
+    cwd = os.getcwd()
+    os.chdir(REF)                                  # random_actions*.py open ./config/<map> in their constructors
+    try:
+        agent = cls(NA, player) if nargs == 2 else cls(NA, player, "DemoMap.json")
+    finally:
+        os.chdir(cwd)
     agent._evg_player = player
     return agent
 
 
-AGENT_POLICY = {"Cycle_BRush_Turn25": 1, "Cycle_BRush_Turn50": 2, "SwarmAgent": 3}
+AGENT_POLICY = {"random_actions": 0, "random_actions_2": 0, "Cycle_BRush_Turn25": 1, "Cycle_BRush_Turn50": 2, "SwarmAgent": 3,
+                "all_cycle": 4, "base_rushV1": 5, "bull_rush": 6, "Cycle_Target_Node": 7, "cycle_targetedNode1": 8,
+                "cycle_targetedNode11": 9, "cycle_targetedNode11P2": 10, "dfs_attack": 11, "NoAction": 12,
+                "random_actions_delay": 13, "same_commands": 14, "same_commands_2": 14}
 
 
 def play_agents(R, seats, seed, env_id, episodes):
@@ -462,6 +496,24 @@ def gen_agent_fixtures(R):
     cyc25, cyc50, swarm = ("cycle_rush_turn25.py", "Cycle_BRush_Turn25"), ("cycle_rush_turn50.py", "Cycle_BRush_Turn50"), ("swarm_agent.py", "SwarmAgent")
     plans = [((cyc25, swarm), 31, 5), ((swarm, cyc25), 32, 9), ((cyc25, swarm), 33, 11), ((swarm, cyc25), 34, 2),
              ((cyc50, swarm), 35, 4), ((swarm, swarm), 36, 6), ((cyc25, cyc25), 37, 8)]
+    # the other State_Machine bots, each on both seats against varied opponents
+    B = dict(rnd=("random_actions.py", "random_actions"), rnd2=("random_actions_2.py", "random_actions_2"),
+             allc=("all_cycle.py", "all_cycle"), brv1=("base_rush_v1.py", "base_rushV1"), bull=("bull_rush.py", "bull_rush"),
+             ctn=("cycle_target_node.py", "Cycle_Target_Node"), ctn1=("cycle_target_node1.py", "cycle_targetedNode1"),
+             ctn11=("cycle_target_node11.py", "cycle_targetedNode11"), ctnp2=("cycle_target_node11P2.py", "cycle_targetedNode11P2"),
+             dfs=("dfs_attack.py", "dfs_attack"), noact=("no_action.py", None), delay=("random_actions_delay.py", "random_actions_delay"),
+             same=("same_commands.py", "same_commands"), same2=("same_commands_2.py", "same_commands_2"))
+    import re
+    noact_src = open(os.path.join(REF, "agents", "State_Machine", "no_action.py")).read()
+    B["noact"] = ("no_action.py", re.search(r"^class (\w+)", noact_src, re.M).group(1))
+    AGENT_POLICY[B["noact"][1]] = 12
+    more = [(("rnd", "rnd2"), 41, 3), (("allc", "rnd"), 42, 7), (("rnd", "allc"), 43, 1), (("brv1", "swarm"), 44, 12), (("swarm", "brv1"), 45, 13),
+            (("bull", "delay"), 46, 14), (("delay", "bull"), 47, 15), (("ctn", "rnd"), 48, 16), (("rnd", "ctn"), 49, 17),
+            (("ctn1", "ctn11"), 50, 18), (("ctn11", "ctn1"), 51, 19), (("ctnp2", "ctnp2"), 52, 20), (("rnd", "ctnp2"), 53, 21),
+            (("dfs", "rnd"), 54, 22), (("rnd", "dfs"), 55, 23), (("noact", "same"), 56, 24), (("same2", "noact"), 57, 25),
+            (("dfs", "dfs"), 58, 26), (("brv1", "cyc25"), 59, 27)]
+    B.update(cyc25=cyc25, cyc50=cyc50, swarm=swarm)
+    plans += [((B[a], B[b]), seed, env_id) for (a, b), seed, env_id in more]
     games = [play_agents(R, seats, seed, env_id, 3) for seats, seed, env_id in plans]
     d = dict(policy=np.array([[AGENT_POLICY[s[1]] for s in seats] for seats, _, _ in plans], np.int32),
              seed=np.array([p[1] for p in plans], np.uint64), env_id=np.array([p[2] for p in plans], np.uint32))
@@ -511,10 +563,13 @@ def main():
     if os.environ.get("EVG_GOLDEN_ONLY") == "agents":
         gen_agent_fixtures(R)
         return
+    only = os.environ.get("EVG_GOLDEN_ONLY")
 
     # 1. full-state trajectories, several policies
     plan = [("random", 6), ("wild", 6), ("rush", 4), ("brawl", 4), ("brawl_v_random", 4), ("rush_v_random", 4)]
     for pi, (pol, cnt) in enumerate(plan):
+        if only and only != pol:
+            continue
         games, metas = [], []
         for i in range(cnt):
             seed, env_id, episode = 1000 + 17 * pi + i, 7 * i + pi, i % 3
@@ -526,6 +581,8 @@ def main():
         stats[pol] = (d["length"].tolist(), [int(s[l - 1]) for s, l in zip(d["status"], d["length"])], R.proxy.draws)
         print(pol, stats[pol], "%.1fs" % (time.time() - t0), flush=True)
 
+    if only:
+        return
     # 2. deterministic KAT (no RNG involved)
     g = R.play("zero", 1, 0, 0, script=kat_script(), max_turns=12)
     np.savez_compressed(os.path.join(OUT, "kat_nocombat.npz"), **pack([g], [dict(policy="kat", seed=1, env_id=0, episode=0)], tmax=12))

@@ -24,13 +24,15 @@ Generator: Philox4x32-10 (Salmon et al., SC'11), 64-bit key, 128-bit counter.
                       (7 distinct groups of 12, 7 distinct nodes of 1..11): blocks 0..3 give 16
                       words; partial Fisher-Yates, see `random_action_rows`.
   swarm   (domain 2): shuffle of the SwarmAgent attack list (swarm_agent.py:86-87), see agents.
+  delay   (domain 3): the `random.random() > 0.68` coin of random_actions_delay.py: word 0 of block 0 as a
+                      fraction of 2^32.
 """
 
 M0, M1 = 0xD2511F53, 0xCD9E8D57
 W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK = 0xFFFFFFFF
 
-DOMAIN_COMBAT, DOMAIN_ACTION, DOMAIN_SWARM = 0, 1, 2
+DOMAIN_COMBAT, DOMAIN_ACTION, DOMAIN_SWARM, DOMAIN_DELAY = 0, 1, 2, 3
 
 
 def philox4x32_10(ctr, key):
@@ -90,6 +92,12 @@ def swarm_shuffle(seed, env_id, episode, turn, player, items):
         j = (words[w] * (i + 1)) >> 32
         items[i], items[j] = items[j], items[i]
     return items
+
+
+def delay_uniform(seed, env_id, episode, turn, player):
+    """Stand-in for random.random() in random_actions_delay.get_action: a float in [0, 1)."""
+    w = philox4x32_10(_ctr(DOMAIN_DELAY, 0, turn, 0, player, episode, env_id), _key(seed))
+    return w[0] / 4294967296.0
 
 
 if __name__ == "__main__":

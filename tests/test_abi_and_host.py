@@ -96,7 +96,7 @@ def test_canonical_actions_follow_the_server(evg):
     assert out.dtype == np.int32 and out.shape == (7, 2)
     assert out.tolist() == [[3, 2], [1, 0], [11, 11], [0, 5], [5, 5], [6, 6], [7, 7]]        # first 7 rows, truncation
     assert ca(np.zeros((3, 2))).tolist() == [[0, 0]] * 7                                      # padded with the invalid order
-    assert ca(np.array([[12, 1], [-1, 3], [3, 40]])).tolist()[:3] == [[12, 1], [-1, 3], [3, 12]]   # out of domain stays invalid
+    assert ca(np.array([[12, 1], [-1, 3], [3, 40], [-13, -12]])).tolist()[:4] == [[99, 1], [-1, 3], [3, 99], [99, -12]]   # Python-list domain
     with pytest.raises(AssertionError):
         ca(np.zeros((7, 3)))
 

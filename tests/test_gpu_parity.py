@@ -178,7 +178,8 @@ def test_single_env_dropin_matches_golden(evg):
     assert sorted(obs.keys()) == [0, 1] and obs[0].dtype == np.float64 and obs[0].shape == (105,)
     env._vec.set_state(*golden_initial_state(d, g))      # this fixture game is episode index d["episode"][g]
     for t in range(int(d["length"][g])):
-        acts = {0: d["actions"][g, t, 0].astype(np.float64) + 0.25, 1: d["actions"][g, t, 1].astype(np.float64)}
+        a0 = d["actions"][g, t, 0].astype(np.float64)
+        acts = {0: np.where(a0 >= 0, a0 + 0.25, a0 - 0.25), 1: d["actions"][g, t, 1].astype(np.float64)}   # astype(int) truncates toward zero
         obs, reward, done, info = env.step(acts)
         assert np.array_equal(obs[0], d["obs"][g, t + 1, 0].astype(np.float64)) and np.array_equal(obs[1], d["obs"][g, t + 1, 1].astype(np.float64))
         assert reward[0] == d["reward"][g, t, 0] and reward[1] == d["reward"][g, t, 1] and done == d["done"][g, t] and info == {}
@@ -340,3 +341,27 @@ def test_native_policy_rollout_equals_stepwise(evg):
         assert np.array_equal(sa[k], sb[k]), k
     assert np.array_equal(a.episode_stats()["totals"], b.episode_stats()["totals"]) and a.episode_stats()["totals"][0] > N
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("pol", list(range(15)))
+def test_every_scripted_bot_vs_oracle(evg, oracle_mod, pol):
+    """All State_Machine bots on device == the oracle's restatement (itself pinned by the reference's
+    classes): bot in seat 0 against random_actions and in seat 1 against swarm, auto-reset, agents alive across episodes."""
+    N, seed, steps = 256, 900 + pol, 230
+    for seats in ((pol, 0), (3, pol)):
+        env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+        ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+        obs, o_obs = env.reset(), ora.reset()
+        for t in range(steps):
+            env.scripted_actions(seats[0], 0)
+            a = env.scripted_actions(seats[1], 1)
+            oa = np.zeros((N, 2, 7, 2), np.int32)
+            ora.scripted_actions(seats[0], 0, o_obs, oa)
+            ora.scripted_actions(seats[1], 1, o_obs, oa)
+            assert np.array_equal(_np(a), oa), ("orders", pol, seats, t)
+            obs, rew, done, info = env.step(a)
+            o_obs, o_rew, o_done, o_info = ora.step(oa)
+            assert np.array_equal(_np(obs).astype(np.float64), o_obs), ("obs", pol, seats, t)
+        check_state(env, ora.get_state(), (pol, seats))
+        assert np.array_equal(env.episode_stats()["totals"], ora.episode_stats()["totals"])
+        env.close()
