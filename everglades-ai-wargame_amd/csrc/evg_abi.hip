@@ -391,6 +391,21 @@ int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, void* stream) {
     return EVG_OK;
 }
 
+int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream) {
+    if (!h || !obs || !features_out || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int rc = launch_smart_state(h->S, player, obs, features_out, h->cfg.obs_dtype, stream);
+    if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+void evg_move_table(int32_t* table /* [11][5] */) {
+    // agents/Smart_State/Move_Translation.py:3-97: node reached from (0-indexed) node n0 in direction 0 left, 1 right, 2 up, 3 down, 4 stay
+    static const int32_t T[5][11] = {{1, 1, 3, 1, 2, 3, 4, 5, 6, 7, 11}, {1, 5, 6, 7, 8, 9, 10, 11, 9, 11, 11}, {2, 2, 2, 3, 5, 6, 7, 8, 8, 9, 8},
+                                     {4, 3, 4, 4, 5, 6, 7, 9, 10, 10, 10}, {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}};
+    for (int n = 0; n < 11; ++n) for (int d = 0; d < 5; ++d) table[n * 5 + d] = T[d][n];
+}
+
 int evg_scripted_reset(evg_handle* h, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));

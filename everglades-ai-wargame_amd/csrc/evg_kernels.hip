@@ -954,6 +954,35 @@ __global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* out) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// 'smart state' preprocessing of agents/Smart_State/DQNAgent.py:200-300: obs[N][2][105] of one player
+// -> features float32 [N][12][59] (the reference builds float64 and the network casts to float32: computed in f64,
+// rounded once).  One thread per output element: fully coalesced stores; the obs row is read through L1/L2.
+// ---------------------------------------------------------------------------------------------
+template <typename OT>
+__global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player, const OT* obs, float* out) {
+    constexpr int F = 59;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)N * NG * F) return;
+    const int f = (int)(idx % F), sw = (int)((idx / F) % NG);
+    const size_t e = idx / ((size_t)F * NG);
+    const OT* o = obs + (e * 2 + player) * OBS;
+    double v = 0.0;
+    if (f == 0) v = (double)o[0] / 150.0;                                             // :280
+    else if (f < 12) v = (double)o[3 + 4 * (f - 1)] / 100.0;                          // :282
+    else if (f < 23) v = (double)o[4 + 4 * (f - 12)] / 100.0;                         // :284
+    else if (f < 34) {                                                                // :200-213, :286
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) cnt += ((int)o[48 + 5 * k] == 0 && (int)o[45 + 5 * k] - 1 == f - 23) ? 1 : 0;
+        v = (double)cnt / 12.0;
+    } else if (f < 45) v = ((int)o[45 + 5 * sw] == f - 34 + 1) ? 1.0 : 0.0;           // :288-292
+    else if (f == 45) v = (double)o[47 + 5 * sw] * (double)o[49 + 5 * sw] / 1000.0;   // :294
+    else if (f == 46) v = (double)o[48 + 5 * sw];                                     // :296
+    else v = (f - 47 == sw) ? 1.0 : 0.0;                                              // :298
+    out[idx] = (float)v;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
@@ -1005,6 +1034,19 @@ int launch_scripted_actions(const DevState& S, int policy, int player, const voi
 
 int launch_scripted_reset(const DevState& S, void* stream) {
     hipLaunchKernelGGL(evg_scripted_reset_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S);
+    return (int)hipGetLastError();
+}
+
+int launch_smart_state(const DevState& S, int player, const void* obs, float* out, int obs_dtype, void* stream) {
+    const size_t total = (size_t)S.N * NG * 59;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (obs_dtype) {
+        case EVG_OBS_F32: hipLaunchKernelGGL(evg_smart_state_kernel<float>, grid, block, 0, s, S.N, player, (const float*)obs, out); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL(evg_smart_state_kernel<double>, grid, block, 0, s, S.N, player, (const double*)obs, out); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL(evg_smart_state_kernel<int16_t>, grid, block, 0, s, S.N, player, (const int16_t*)obs, out); break;
+        default: return -1;
+    }
     return (int)hipGetLastError();
 }
 

@@ -150,6 +150,23 @@ class EvergladesVecEnv(object):
         _lib.check(self.L.evg_fog_of_war(self._h, self._ptr(out), self._stream()))
         return out
 
+    def smart_state(self, player, obs=None, out=None):
+        """float32 [N, 12, 59]: the per-swarm input of the reference's Smart_State agents (DQNAgent.create_swarm_obs) for
+        seat `player`, computed on device from `obs` (default: the env's observation buffer)."""
+        torch = _torch()
+        obs = self.obs if obs is None else obs
+        if out is None:
+            out = torch.empty((self.num_envs, _lib.NUM_GROUPS, 59), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.evg_smart_state(self._h, int(player), self._ptr(obs), self._ptr(out), self._stream()))
+        return out
+
+    @staticmethod
+    def move_table():
+        """int32 [11, 5]: Move_Translation.get_move(node0, direction) as a lookup table (directions left, right, up, down, stay)."""
+        t = np.zeros((11, 5), np.int32)
+        _lib.load().evg_move_table(t.ctypes.data_as(C.c_void_p))
+        return t
+
     def random_actions(self, out=None):
         """On-device equivalent of agents/State_Machine/random_actions.py for both players of every env."""
         out = self._actions if out is None else out

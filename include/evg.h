@@ -145,6 +145,14 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream);
  * order, not mirrored for player 1, exactly as the reference computes it. */
 int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, void* stream);
 
+/* Consumer-side preprocessing of the reference's strongest agent family (agents/Smart_State/DQNAgent.py:200-300,
+ * create_swarm_obs): from `player`'s rows of obs (device [N][2][105] of cfg.obs_dtype) to features_out, device float
+ * [N][12][59]: per swarm {turn/150, 11 x control/100, 11 x enemy units/100, 11 x idle allied groups/12, one-hot node,
+ * avg health x alive / 1000, in transit, one-hot swarm id}; each value is the reference's float64 expression rounded to
+ * float32.  evg_move_table fills table[11][5] with Move_Translation.get_move(node0, direction) (host memory). */
+int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream);
+void evg_move_table(int32_t* table);
+
 /* Input generator for the benchmark configs: the on-device equivalent of
  * agents/State_Machine/random_actions.py:38-46 for every env and both players, keyed by
  * (seed, env id, episode, turn, player).  actions_out: device int32 [N][2][7][2]. */

@@ -523,6 +523,32 @@ def gen_agent_fixtures(R):
     print("agents:", d["length"].tolist(), d["status"].tolist(), flush=True)
 
 
+def gen_smart_state_fixture():
+    """the per-swarm 'smart state' preprocessing of agents/Smart_State/DQNAgent.py:200-300 and the move
+    table of Move_Translation.py, evaluated by the reference's own functions on observations of committed trajectories."""
+    sys.path.insert(0, REF)
+    import agents.Smart_State.DQNAgent as D
+    ns = types.SimpleNamespace(num_nodes=NN)
+    obs_list = []
+    for f in ("traj_brawl_v_random.npz", "traj_rush_v_random.npz", "traj_wild.npz"):
+        d = np.load(os.path.join(OUT, f))
+        for g in range(2):
+            for t in range(0, int(d["length"][g]) + 1, 7):
+                obs_list.append(d["obs"][g, t].astype(np.float64))
+    obs = np.stack(obs_list)                                   # [M, 2, 105]
+    feats = np.zeros((obs.shape[0], 2, NG, D.INPUT_SIZE), np.float64)
+    allies = np.zeros((obs.shape[0], 2, NN), np.float64)
+    for m in range(obs.shape[0]):
+        for p in range(2):
+            al = D.DQNAgent.get_allies_on_node_data(ns, obs[m, p])
+            allies[m, p] = al
+            for sw in range(NG):
+                feats[m, p, sw] = D.DQNAgent.create_swarm_obs(ns, sw, obs[m, p], al)
+    moves = np.array([[D.get_move(n0, d_) for d_ in range(5)] for n0 in range(NN)], np.int32)     # [node0][direction] -> node id
+    np.savez_compressed(os.path.join(OUT, "smart_state.npz"), obs=obs.astype(np.int16), features=feats, allies=allies, moves=moves)
+    print("smart_state:", feats.shape, moves.tolist(), flush=True)
+
+
 # ----------------------------------------------------------------------------------------------
 def kat_script():
     """deterministic no-combat trajectory."""
@@ -563,6 +589,9 @@ def main():
     if os.environ.get("EVG_GOLDEN_ONLY") == "agents":
         gen_agent_fixtures(R)
         return
+    if os.environ.get("EVG_GOLDEN_ONLY") == "smart":
+        gen_smart_state_fixture()
+        return
     only = os.environ.get("EVG_GOLDEN_ONLY")
 
     # 1. full-state trajectories, several policies
@@ -595,6 +624,8 @@ def main():
 
     # 3b. scripted agents of BASELINE config 5 (the reference's own agent classes produce the action streams)
     gen_agent_fixtures(R)
+
+    gen_smart_state_fixture()
 
     # 4. bulk random-vs-random: outcomes + per-turn checksums only
     B = 120

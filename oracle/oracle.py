@@ -82,6 +82,9 @@ def lib():
         L.evo_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.evo_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.evo_observe.argtypes = [C.c_void_p, C.c_void_p]
+        L.evo_smart_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.evo_get_move.restype = C.c_int
+        L.evo_get_move.argtypes = [C.c_int, C.c_int]
         L.evo_fog_of_war.argtypes = [C.c_void_p, C.c_void_p]
         L.evo_scripted_actions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.evo_scripted_reset.argtypes = [C.c_void_p]
@@ -191,6 +194,18 @@ class Oracle(object):
         tot = np.zeros(4, np.int64)
         self.L.evo_episode_stats(self.h, _p(r), _p(ln), _p(w), _p(tot))
         return dict(returns=r, length=ln, winner=w, totals=tot)
+
+
+def smart_state(obs_rows):
+    """obs_rows [m, 105] (one player's observations) -> [m, 12, 59] float64 (DQNAgent.create_swarm_obs)."""
+    o = np.ascontiguousarray(obs_rows, np.float64)
+    out = np.zeros((o.shape[0], NG, 59), np.float64)
+    lib().evo_smart_state(_p(o), o.shape[0], _p(out))
+    return out
+
+
+def get_move(node0, direction):
+    return lib().evo_get_move(int(node0), int(direction))
 
 
 def np_sum(a):

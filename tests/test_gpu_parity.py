@@ -365,3 +365,18 @@ def test_every_scripted_bot_vs_oracle(evg, oracle_mod, pol):
         check_state(env, ora.get_state(), (pol, seats))
         assert np.array_equal(env.episode_stats()["totals"], ora.episode_stats()["totals"])
         env.close()
+
+
+def test_smart_state_features_match_reference_fixture(evg):
+    """device features == float32(reference float64 features) bit for bit, for every obs dtype."""
+    import torch
+    d = load_golden("smart_state.npz")
+    M = d["obs"].shape[0]
+    assert np.array_equal(evg.EvergladesVecEnv.move_table(), d["moves"])
+    for dt, tdt in (("float32", torch.float32), ("float64", torch.float64), ("int16", torch.int16)):
+        env = evg.EvergladesVecEnv(M, seed=1, obs_dtype=dt)
+        obs = torch.as_tensor(d["obs"].astype(np.int64), device=env.device).to(tdt).contiguous()
+        for p in range(2):
+            f = _np(env.smart_state(p, obs))
+            assert np.array_equal(f, d["features"][:, p].astype(np.float32)), (dt, p)
+        env.close()

@@ -27,3 +27,14 @@ def test_scripted_agents_match_reference(oracle_mod):
                 obs, rew, done, info = o.step(a)
             assert done[0] == 1 and info["status"][0] == d["status"][g, ep] and np.array_equal(info["scores"][0], d["scores"][g, ep])
             assert np.array_equal(obs[0], d["obs"][g, ep, T].astype(np.float64))
+
+
+def test_smart_state_features_match_reference(oracle_mod):
+    """create_swarm_obs / get_allies_on_node_data (DQNAgent.py:200-300) and Move_Translation.get_move."""
+    d = load_golden("smart_state.npz")
+    obs = d["obs"].astype(np.float64)
+    for p in range(2):
+        f = oracle_mod.smart_state(obs[:, p])
+        assert np.array_equal(f, d["features"][:, p]), p
+        assert np.array_equal(f[:, 0, 23:34] * 12.0, d["allies"][:, p])
+    assert [[oracle_mod.get_move(n, k) for k in range(5)] for n in range(11)] == d["moves"].tolist()
