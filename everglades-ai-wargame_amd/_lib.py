@@ -76,7 +76,7 @@ def load():
     L.evg_reset.argtypes = [vp, vp, vp, vp]
     L.evg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.evg_observe.argtypes = [vp, vp, vp]
-    L.evg_fog_of_war.argtypes = [vp, vp, vp]
+    L.evg_fog_of_war.argtypes = [vp, vp, vp, vp]
     L.evg_smart_state.argtypes = [vp, C.c_int, vp, vp, vp]
     L.evg_move_table.argtypes = [vp]
     L.evg_move_table.restype = None

@@ -927,30 +927,43 @@ __global__ void evg_scripted_reset_kernel(DevState S) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// fog-of-war mask of board_state (server.py:402-425): the reference computes `valid_nodes` and never
-// applies it; exposed here as an optional observation plane.  One thread per (env, player); real node order.
+// fog-of-war planes: the `valid_nodes` mask of board_state (server.py:402-425) and the per-node knowledge
+// levels of build_knowledge_output (server.py:779-832) -- both computed by the reference and never applied to the
+// observation; exposed here as optional planes.  One thread per (env, player); real node order.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* out) {
+__global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* fog, uint8_t* know) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 2 * S.N) return;
     const int e = idx >> 1, p = idx & 1;
     const size_t N = (size_t)S.N;
     const DevTables* __restrict__ T = S.T;
-    uint32_t valid = 0;
+    uint32_t ctrl = 0, watch = 0;          // nodes controlled by p; of those, fully controlled OBSERVE nodes
+    uint32_t seen_by_tower = 0;
 #pragma unroll
     for (int n = 1; n <= NN; ++n) {
-        const int cb = (int)((S.node[(size_t)(n - 1) * N + e] >> 10) & 3u) - 1;
-        if (cb == p) valid |= (1u << n) | ((T->resource[n] & EVG_RES_OBSERVE) ? T->nbr_mask[n] : 0u);   // :411-418
+        const uint32_t nw = S.node[(size_t)(n - 1) * N + e];
+        const int cb = (int)((nw >> 10) & 3u) - 1, cs = (int)(nw & 0x3FFu) - 512;
+        const bool mine = cb == p, obs = (T->resource[n] & EVG_RES_OBSERVE) != 0;
+        ctrl |= (mine ? 1u : 0u) << n;
+        seen_by_tower |= (mine && obs) ? T->nbr_mask[n] : 0u;                                        // :415-418
+        watch |= (mine && obs && abs(cs) == T->control_points[n]) ? T->nbr_mask[n] : 0u;              // server.py:801-804
     }
+    uint32_t idle = 0, incoming = 0;       // nodes with a listed non-moving group of p; nodes a group of p moves to from a neighbour
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {                                                                      // :421-424
+    for (int k = 0; k < 12; ++k) {
         const uint32_t w = S.grp[(size_t)(p * 12 + k) * N + e];
-        const bool listed_idle = (w & G_MASK_M) != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;
-        valid |= (listed_idle ? 1u : 0u) << (w & G_LOC_M);
+        const bool alive = (w & G_MASK_M) != 0, moving = ((w & G_MODE_M) >> G_MODE_S) == MODE_MOVING;
+        const uint32_t loc = w & G_LOC_M, dest = (w & G_DEST_M) >> G_DEST_S;
+        idle |= ((alive && !moving) ? 1u : 0u) << loc;                                                // :421-424, :784-787
+        incoming |= ((alive && moving && ((T->nbr_mask[dest] >> loc) & 1u)) ? 1u : 0u) << dest;       // :806-812
     }
-    uint8_t* o = out + (size_t)idx * NN;
+    const uint32_t valid = ctrl | seen_by_tower | idle;                                               // board_state :402-425
+    const uint32_t full = ctrl | idle, partial = watch | incoming;                                    // build_knowledge_output :816-829
 #pragma unroll
-    for (int n = 1; n <= NN; ++n) o[n - 1] = (uint8_t)((valid >> n) & 1u);
+    for (int n = 1; n <= NN; ++n) {
+        if (fog) fog[(size_t)idx * NN + n - 1] = (uint8_t)((valid >> n) & 1u);
+        if (know) know[(size_t)idx * NN + n - 1] = (uint8_t)(((full >> n) & 1u) ? 2u : (((partial >> n) & 1u) ? 1u : 0u));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1050,8 +1063,8 @@ int launch_smart_state(const DevState& S, int player, const void* obs, float* ou
     return (int)hipGetLastError();
 }
 
-int launch_fog(const DevState& S, uint8_t* out, void* stream) {
-    hipLaunchKernelGGL(evg_fog_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, out);
+int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, void* stream) {
+    hipLaunchKernelGGL(evg_fog_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, fog, know);
     return (int)hipGetLastError();
 }
 

@@ -147,7 +147,17 @@ class EvergladesVecEnv(object):
             if getattr(self, "_fog", None) is None:
                 self._fog = torch.zeros((self.num_envs, 2, _lib.NUM_NODES), dtype=torch.uint8, device=self.device)
             out = self._fog
-        _lib.check(self.L.evg_fog_of_war(self._h, self._ptr(out), self._stream()))
+        _lib.check(self.L.evg_fog_of_war(self._h, self._ptr(out), None, self._stream()))
+        return out
+
+    def knowledge(self, out=None):
+        """uint8 [N, 2, 11]: node knowledge levels 0/1/2 of build_knowledge_output (server.py:779-832)."""
+        torch = _torch()
+        if out is None:
+            if getattr(self, "_know", None) is None:
+                self._know = torch.zeros((self.num_envs, 2, _lib.NUM_NODES), dtype=torch.uint8, device=self.device)
+            out = self._know
+        _lib.check(self.L.evg_fog_of_war(self._h, None, self._ptr(out), self._stream()))
         return out
 
     def smart_state(self, player, obs=None, out=None):

@@ -139,11 +139,15 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
  * the board_state/player_state half of step (server.py:382-501). obs_out as in evg_step. */
 int evg_observe(evg_handle* h, void* obs_out, void* stream);
 
-/* Fog-of-war plane of the current state: the `valid_nodes` mask that board_state computes and then never applies
- * (server.py:402-425).  fog_out: device uint8 [N][2][11], entry [e][p][i] = 1 iff player p sees node ID i+1 (a node
- * it controls, a neighbour of a controlled OBSERVE node, or a node where it has a non-moving group).  Real node
- * order, not mirrored for player 1, exactly as the reference computes it. */
-int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, void* stream);
+/* Fog-of-war planes of the current state, both computed by the reference and never applied to its observations:
+ *   fog_out        device uint8 [N][2][11] or NULL: the `valid_nodes` mask of board_state (server.py:402-425);
+ *                  [e][p][i] = 1 iff player p sees node ID i+1 (a node it controls, a neighbour of a controlled OBSERVE
+ *                  node, or a node where it has a non-moving group)
+ *   knowledge_out  device uint8 [N][2][11] or NULL: the knowledge level of build_knowledge_output (server.py:779-832):
+ *                  2 full (controlled, or a non-moving group there), 1 partial (next to a fully controlled OBSERVE node
+ *                  of the player, or one of its groups is moving there), 0 none
+ * Real node order, not mirrored for player 1, exactly as the reference computes them. */
+int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void* stream);
 
 /* Consumer-side preprocessing of the reference's strongest agent family (agents/Smart_State/DQNAgent.py:200-300,
  * create_swarm_obs): from `player`'s rows of obs (device [N][2][105] of cfg.obs_dtype) to features_out, device float

@@ -141,6 +141,30 @@ class FogTap(object):
         return np.array([self.last[0], self.last[1]], np.uint8)
 
 
+def knowledge_levels(game):
+    """The per-node knowledge levels (0 none, 1 partial, 2 full) that build_knowledge_output (server.py:769-835) computes
+    into a local list and only formats into a dropped string.  The function mutates nothing, so it is called once per
+    player (team_starts temporarily narrowed to that player) with a profiler hook reading the local at return."""
+    out = np.zeros((2, NN), np.uint8)
+    saved = game.team_starts
+    for pid in (0, 1):
+        box = {}
+
+        def hook(frame, event, arg, _b=box):
+            if event == "return" and frame.f_code.co_name == "build_knowledge_output":
+                _b["k"] = list(frame.f_locals["knowledge"])
+
+        game.team_starts = {pid: saved[pid]}
+        sys.setprofile(hook)
+        try:
+            game.build_knowledge_output()
+        finally:
+            sys.setprofile(None)
+            game.team_starts = saved
+        out[pid] = box["k"]
+    return out
+
+
 class Tracker(object):
     """Follows one reference game and dumps the canonical state (tests/README of the layout:
     groups[2][12][8] = loc,dest,dist,ready,moving,destroyed,count,stamp; nodes[11][2] =
@@ -319,7 +343,7 @@ class Runner(object):
                for p in (0, 1)]
         pols = POLICIES[policy] if policy in POLICIES else (pol_zero, pol_zero)
         rec = dict(obs=[np.stack([obs[0], obs[1]])], actions=[], raw0=[], raw1=[], reward=[], done=[], scores=[],
-                   status=[], groups=[], nodes=[], health=[], rank=[], fog=[tap.snapshot()])
+                   status=[], groups=[], nodes=[], health=[], rank=[], fog=[tap.snapshot()], know=[knowledge_levels(game)])
         g, n, h, r = tr.snapshot()
         rec["groups"].append(g), rec["nodes"].append(n), rec["health"].append(h), rec["rank"].append(r)
         done, t = 0, 0
@@ -342,6 +366,7 @@ class Runner(object):
                 obs, reward, done, info = self.env.step({0: a0, 1: a1})
             game.game_turn = orig
             rec["fog"].append(tap.snapshot())
+            rec["know"].append(knowledge_levels(game))
             tr.after_turn()
             t += 1
             rec["actions"].append(np.stack([canon_actions(a0), canon_actions(a1)]))
@@ -353,7 +378,7 @@ class Runner(object):
             g, n, h, r = tr.snapshot()
             rec["groups"].append(g), rec["nodes"].append(n), rec["health"].append(h), rec["rank"].append(r)
         out = dict(length=t)
-        for k in ("obs", "actions", "reward", "done", "scores", "status", "groups", "nodes", "health", "rank", "fog"):
+        for k in ("obs", "actions", "reward", "done", "scores", "status", "groups", "nodes", "health", "rank", "fog", "know"):
             out[k] = np.array(rec[k])
         assert np.all(out["obs"] == np.round(out["obs"])) and np.abs(out["obs"]).max() <= 500
         return out
@@ -371,13 +396,13 @@ def pack(games, metas, tmax=150):
         scores=np.zeros((G, tmax, 2), np.int32), status=np.zeros((G, tmax), np.uint8),
         groups=np.zeros((G, tmax + 1, 2, NG, 8), np.int16), nodes=np.zeros((G, tmax + 1, NN, 2), np.int16),
         health=np.zeros((G, tmax + 1, 2, NU), np.float64), rank=np.zeros((G, tmax + 1, 2, NG), np.int8),
-        fog=np.zeros((G, tmax + 1, 2, NN), np.uint8))
+        fog=np.zeros((G, tmax + 1, 2, NN), np.uint8), know=np.zeros((G, tmax + 1, 2, NN), np.uint8))
     for i, g in enumerate(games):
         T = g["length"]
         d["obs"][i, :T + 1] = g["obs"]
         for k in ("actions", "reward", "done", "scores", "status"):
             d[k][i, :T] = g[k]
-        for k in ("groups", "nodes", "health", "rank", "fog"):
+        for k in ("groups", "nodes", "health", "rank", "fog", "know"):
             d[k][i, :T + 1] = g[k]
     return d
 

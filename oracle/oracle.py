@@ -86,6 +86,7 @@ def lib():
         L.evo_get_move.restype = C.c_int
         L.evo_get_move.argtypes = [C.c_int, C.c_int]
         L.evo_fog_of_war.argtypes = [C.c_void_p, C.c_void_p]
+        L.evo_knowledge.argtypes = [C.c_void_p, C.c_void_p]
         L.evo_scripted_actions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.evo_scripted_reset.argtypes = [C.c_void_p]
         L.evo_episode_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
@@ -165,6 +166,11 @@ class Oracle(object):
     def fog_of_war(self):
         f = np.zeros((self.n, NP, NN), np.uint8)
         self.L.evo_fog_of_war(self.h, _p(f))
+        return f
+
+    def knowledge(self):
+        f = np.zeros((self.n, NP, NN), np.uint8)
+        self.L.evo_knowledge(self.h, _p(f))
         return f
 
     def observe(self):

@@ -50,6 +50,7 @@ def test_golden_through_abi(evg, fname):
             assert np.array_equal(s["groups"][0], d["groups"][g, t + 1]), ("groups", fname, g, t)
             assert np.array_equal(s["nodes"][0], d["nodes"][g, t + 1]), ("nodes", fname, g, t)
             assert np.array_equal(_np(env.fog_of_war())[0], d["fog"][g, t + 1]), ("fog-of-war mask", fname, g, t)
+            assert np.array_equal(_np(env.knowledge())[0], d["know"][g, t + 1]), ("knowledge levels", fname, g, t)
         env.close()
 
 
@@ -92,7 +93,7 @@ def test_random_rollout_vs_oracle(evg, oracle_mod, N):
         assert np.allclose(_np(rew), o_rew, rtol=0, atol=REWARD_ATOL)
         if t % 25 == 0 or t >= 149:
             check_state(env, ora.get_state(), t)
-            assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war())
+            assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.knowledge()), ora.knowledge())
     st, ost = env.episode_stats(), ora.episode_stats()
     assert np.array_equal(st["totals"], ost["totals"]) and np.array_equal(st["winner"], ost["winner"])
     assert np.array_equal(st["length"], ost["length"]) and np.allclose(st["returns"], ost["returns"], rtol=1e-6, atol=1e-5)

@@ -18,6 +18,7 @@ def replay(om, d, g, check_state=True):
         obs = o.observe()
     assert np.array_equal(obs[0], d["obs"][g, 0].astype(np.float64)), "reset obs"
     assert np.array_equal(o.fog_of_war()[0], d["fog"][g, 0]), "fog-of-war mask at reset"
+    assert np.array_equal(o.knowledge()[0], d["know"][g, 0]), "knowledge levels at reset"
     for t in range(T):
         obs, reward, done, info = o.step(d["actions"][g, t][None].astype(np.int32))
         assert np.array_equal(obs[0], d["obs"][g, t + 1].astype(np.float64)), ("obs", g, t)
@@ -32,6 +33,7 @@ def replay(om, d, g, check_state=True):
             assert np.array_equal(s["nodes"][0], d["nodes"][g, t + 1]), ("nodes", g, t)
             assert np.array_equal(s["rank"][0], d["rank"][g, t + 1]), ("node list order", g, t)
             assert np.array_equal(o.fog_of_war()[0], d["fog"][g, t + 1]), ("fog-of-war mask (server.py:402-425)", g, t)
+            assert np.array_equal(o.knowledge()[0], d["know"][g, t + 1]), ("knowledge levels (server.py:779-832)", g, t)
     return o
 
 
