@@ -548,6 +548,23 @@ def gen_agent_fixtures(R):
     print("agents:", d["length"].tolist(), d["status"].tolist(), flush=True)
 
 
+def gen_stock_mt_fixture(R):
+    """the reference with NO entropy injection -- np.random.seed(s) and its own np.random.randint at
+    server.py:205,338,562 -- driven by action streams that do not touch numpy's generator."""
+    R.server.np = np                                     # undo the proxy: the stock module-global numpy
+    games, metas = [], []
+    for i, pol in enumerate(["random", "random", "brawl", "brawl_v_random", "rush_v_random", "wild", "random", "brawl"]):
+        seed = 7000 + 13 * i
+        np.random.seed(seed)
+        g = R.play(pol, seed, 100 + i, 0)
+        games.append(g)
+        metas.append(dict(policy=pol, seed=seed, env_id=100 + i, episode=0))
+    R.server.np = R.proxy
+    d = pack(games, metas)
+    np.savez_compressed(os.path.join(OUT, "stock_mt.npz"), **d)
+    print("stock_mt:", d["length"].tolist(), [int(s[l - 1]) for s, l in zip(d["status"], d["length"])], flush=True)
+
+
 def gen_smart_state_fixture():
     """the per-swarm 'smart state' preprocessing of agents/Smart_State/DQNAgent.py:200-300 and the move
     table of Move_Translation.py, evaluated by the reference's own functions on observations of committed trajectories."""
@@ -614,6 +631,9 @@ def main():
     if os.environ.get("EVG_GOLDEN_ONLY") == "agents":
         gen_agent_fixtures(R)
         return
+    if os.environ.get("EVG_GOLDEN_ONLY") == "stock":
+        gen_stock_mt_fixture(R)
+        return
     if os.environ.get("EVG_GOLDEN_ONLY") == "smart":
         gen_smart_state_fixture()
         return
@@ -651,6 +671,7 @@ def main():
     gen_agent_fixtures(R)
 
     gen_smart_state_fixture()
+    gen_stock_mt_fixture(R)
 
     # 4. bulk random-vs-random: outcomes + per-turn checksums only
     B = 120

@@ -82,6 +82,8 @@ def lib():
         L.evo_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.evo_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.evo_observe.argtypes = [C.c_void_p, C.c_void_p]
+        L.evo_use_stock_mt.argtypes = [C.c_void_p, C.c_void_p]
+        L.evo_mt_randint_stream.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.evo_smart_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.evo_get_move.restype = C.c_int
         L.evo_get_move.argtypes = [C.c_int, C.c_int]
@@ -151,6 +153,13 @@ class Oracle(object):
         self.L.evo_random_actions(self.h, _p(a))
         return a
 
+    def use_stock_mt(self, seeds):
+        """Switch to numpy's legacy global generator per env (np.random.seed(seeds[e])): SURVEY 8 f2, validation only.
+        Call before reset()."""
+        sd = np.ascontiguousarray(seeds, np.uint32)
+        assert sd.shape == (self.n,)
+        self.L.evo_use_stock_mt(self.h, _p(sd))
+
     def scripted_actions(self, policy, player, obs, out=None):
         """policy: 1 Cycle_BRush_Turn25, 2 Cycle_BRush_Turn50, 3 SwarmAgent; writes rows [:, player] of `out`."""
         o = np.ascontiguousarray(obs, np.float64)
@@ -212,6 +221,13 @@ def smart_state(obs_rows):
 
 def get_move(node0, direction):
     return lib().evo_get_move(int(node0), int(direction))
+
+
+def mt_randint_stream(seed, ns):
+    ns = np.ascontiguousarray(ns, np.int32)
+    out = np.zeros(ns.size, np.int32)
+    lib().evo_mt_randint_stream(int(seed), _p(ns), ns.size, _p(out))
+    return out
 
 
 def np_sum(a):

@@ -134,3 +134,34 @@ def test_np_sum_model(oracle_mod):
         for _ in range(20000):
             a = np.where(r.random(n) < 0.3, 0.0, r.random(n) * 100.0)
             assert np.sum(a) == oracle_mod.np_sum(a)
+
+
+def test_numpy_legacy_randint_model(oracle_mod):
+    """np.random.seed(s); np.random.randint(n): MT19937 init_genrand + masked rejection over 32-bit outputs,
+    nothing consumed for n == 1 (what the reference's three draw sites use, server.py:205,338,562)."""
+    r = np.random.default_rng(3)
+    for seed in (0, 1, 12345, 2 ** 32 - 1):
+        ns = r.integers(1, 101, 4000).astype(np.int32)
+        np.random.seed(seed)
+        want = np.array([np.random.randint(int(n)) for n in ns], np.int32)
+        assert np.array_equal(oracle_mod.mt_randint_stream(seed, ns), want), seed
+
+
+def test_unmodified_reference_with_stock_entropy(oracle_mod):
+    """SURVEY 8 f2 at oracle level: tests/golden/stock_mt.npz was produced by the reference with NO entropy injection
+    (np.random.seed(s), its own np.random.randint incl. the two unobservable focus draws).  The oracle in stock mode --
+    same draw ORDER over nodes, players, list-ordered groups and units -- reproduces every observation, score and the
+    float64 health bit for bit."""
+    d = load_golden("stock_mt.npz")
+    for g in range(len(d["length"])):
+        o = oracle_mod.Oracle(1, seed=0, env_id_base=0)
+        o.use_stock_mt([int(d["seed"][g])])
+        obs = o.reset()
+        assert np.array_equal(obs[0], d["obs"][g, 0].astype(np.float64))
+        for t in range(int(d["length"][g])):
+            obs, reward, done, info = o.step(d["actions"][g, t][None].astype(np.int32))
+            assert np.array_equal(obs[0], d["obs"][g, t + 1].astype(np.float64)), ("obs", g, t)
+            assert np.array_equal(info["scores"][0], d["scores"][g, t]) and info["status"][0] == d["status"][g, t]
+            s = o.get_state()
+            assert np.array_equal(s["health"][0], d["health"][g, t + 1]), ("health bits", g, t)
+            assert np.array_equal(s["rank"][0], d["rank"][g, t + 1])
