@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--obs-dtype", default="float32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--turns-per-launch", type=int, default=150,
+                    help="random workload: consecutive turns each wavefront plays per launch of the step kernel (persistent rollout form; "
+                         "1 = one launch per turn). Outputs are written every turn in both forms and the results are identical.")
     ap.add_argument("--workload", default="random", choices=["random", "scripted"],
                     help="random: BASELINE metric config (random vs random); scripted: BASELINE config 5 (cycle_rush_turn25 vs swarm)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -145,7 +148,8 @@ def main():
             dist.barrier(device_ids=[dev_index]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(device)
 
-    def run(nsteps, timed):
+    def run(nsteps, timed, tpl=None):
+        tpl = args.turns_per_launch if tpl is None else tpl
         """nsteps turns through the native rollout driver (evg_rollout_random: per turn the random_actions kernel then
         the step kernel, enqueued from C on torch's current stream), split at episode boundaries (every 150 turns for
         random vs random) where the episode results are gathered.  Returns the summed step-kernel time in ms (HIP
@@ -155,14 +159,14 @@ def main():
         left = nsteps
         while left > 0:
             chunk = min(left, period - turn_counter % period)
-            out = (env.rollout_random(chunk, time_kernel=timed) if args.workload == "random" else
+            out = (env.rollout_random(chunk, time_kernel=timed, turns_per_launch=tpl) if args.workload == "random" else
                    env.rollout_policies(chunk, "cycle_rush_turn25", "swarm", time_kernel=timed))
             if timed:
                 kernel_ms_sum += out[-1] * chunk
             turn_counter += chunk
             left -= chunk
             if turn_counter % period == 0:
-                gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total)
+                gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
         return kernel_ms_sum, gathered
 
     turn_counter = 0
@@ -180,6 +184,16 @@ def main():
         dt = float(tmax.item())
     step_kernel_ms = kernel_ms_sum / args.steps
 
+    # for reference, outside the timed region: the same rollout with one launch per turn (what env.step() costs per call)
+    per_turn_launch = None
+    if args.workload == "random" and args.turns_per_launch > 1 and world == 1:
+        barrier()
+        t1 = time.perf_counter()
+        k1, _ = run(150, True, tpl=1)
+        barrier()
+        d1 = time.perf_counter() - t1
+        per_turn_launch = {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": k1 / 150}
+
     if rank == 0:
         value = total * args.steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9
@@ -191,20 +205,22 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": ("%d concurrent DemoMap games per GPU, random_actions vs random_actions drawn on device (fused into the "
-                                    "step kernel, orders written to an [N,2,7,2] tensor), auto-reset, obs %s [N,2,105]" if args.workload == "random" else
+                                    "step kernel, orders written to an [N,2,7,2] tensor; persistent rollout form, see turns_per_launch), auto-reset, obs %s [N,2,105]" if args.workload == "random" else
                                     "%d concurrent DemoMap games per GPU, on-device Cycle_BRush_Turn25 vs SwarmAgent (BASELINE config 5; episodes end by "
                                     "BaseCapture after 84-94 turns), auto-reset, obs %s [N,2,105]") % (n_local, args.obs_dtype),
-                       "envs_per_gpu": n_local, "total_envs": total, "parallelism": "env-sharded x%d" % world,
+                       "envs_per_gpu": n_local, "total_envs": total,
+                       "turns_per_launch": args.turns_per_launch if args.workload == "random" else 1,
+                       "one_launch_per_turn": per_turn_launch, "parallelism": "env-sharded x%d" % world,
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
-                       "gathered_wins_all_ranks": list(gathered["wins"]) if gathered is not None else None},
+                       "gathered_wins_all_ranks": list(evg.win_counts(gathered)) if gathered is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "achieved_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
                          "measured_traffic_GBps": (traffic / (step_kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "note": "achieved uses the ALGORITHMIC bytes of SURVEY 8(d); it exceeds 1.0 of peak when the kernel moves fewer "
                                  "bytes than that accounting (health rows are only touched where combat hits): compare traffic",
-                         "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms,
+                         "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms, "kernel_ms_is": "launch duration / turns played by the launch",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
         }
         if world == 1 and not args.no_cpu_baseline:

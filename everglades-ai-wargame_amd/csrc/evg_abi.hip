@@ -351,7 +351,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, nullptr, h->stamps, h->lanes, h->ablate};
+    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, nullptr, h->stamps, 1, h->lanes, h->ablate};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -360,7 +360,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
 int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, h->lanes, 0};
+    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, 1, h->lanes, 0};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -438,6 +438,40 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
     if (steps < 1 || !actions_buf || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, actions_buf, reward_out, done_out required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipStream_t s_ = s;
+    const bool random_pair = policy0 == EVG_POLICY_RANDOM && policy1 == EVG_POLICY_RANDOM;
+    if (random_pair && fused >= 2) {
+        // Persistent form: one launch plays up to `fused` consecutive turns per wavefront (state stays on chip, outputs are
+        // written every turn).  step_kernel_ms then is the launch time divided by the turns it played.
+        const int per_launch = fused;
+        const int nlaunch = (steps + per_launch - 1) / per_launch;
+        while (step_kernel_ms && h->events.size() < (size_t)2 * nlaunch) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            h->events.push_back(ev);
+        }
+        StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 1, actions_buf, h->stamps, 1, h->lanes, h->ablate};
+        int done_turns = 0;
+        for (int l = 0; l < nlaunch; ++l) {
+            io.turns = steps - done_turns < per_launch ? steps - done_turns : per_launch;
+            if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l], s_));
+            const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
+            if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
+            if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l + 1], s_));
+            done_turns += io.turns;
+        }
+        if (step_kernel_ms) {
+            HIP_TRY(hipStreamSynchronize(s_));
+            double tot = 0.0;
+            for (int l = 0; l < nlaunch; ++l) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, h->events[2 * l], h->events[2 * l + 1]));
+                tot += ms;
+            }
+            *step_kernel_ms = (float)(tot / steps);
+        }
+        return EVG_OK;
+    }
     // Event pairs make the queue wait for each bracketed kernel to retire, so only every 8th launch is bracketed:
     // the sample prices the kernel, the unbracketed launches keep the stream back-to-back.
     constexpr int kSampleEvery = 8;
@@ -447,10 +481,10 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         HIP_TRY(hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? 1 : 0, actions_buf, h->stamps, h->lanes, h->ablate};
+    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, (fused && random_pair) ? 1 : 0, actions_buf, h->stamps, 1, h->lanes, h->ablate};
     for (int i = 0; i < steps; ++i) {
         int rc = 0;
-        if (policy0 == EVG_POLICY_RANDOM && policy1 == EVG_POLICY_RANDOM) {
+        if (random_pair) {
             if (!fused) rc = launch_random_actions(h->S, actions_buf, stream);
         } else {                                  // the agents read the observations of the previous turn from obs_out
             rc = launch_scripted_actions(h->S, policy0, 0, obs_out, actions_buf, h->cfg.obs_dtype, stream);
@@ -458,13 +492,13 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         }
         if (rc) return fail(EVG_ERR_HIP, "action kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
         const bool sample = step_kernel_ms && i % kSampleEvery == 0;
-        if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery)], s));
+        if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery)], s_));
         rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
         if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
-        if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery) + 1], s));
+        if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery) + 1], s_));
     }
     if (step_kernel_ms) {
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipStreamSynchronize(s_));
         double tot = 0.0;
         for (int i = 0; i < nsamples; ++i) {
             float ms = 0.f;

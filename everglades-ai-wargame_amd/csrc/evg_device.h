@@ -92,6 +92,7 @@ struct StepIO {
     int32_t   gen_actions;       // 1: draw both players' orders in the kernel (random_actions policy) instead of reading `actions`
     int32_t*  actions_out;       //    ... and store them here ([N][2][7][2], may be NULL)
     unsigned long long* stamps;  // diagnostic build (EVG_STAMPS) only, else NULL
+    int32_t   turns;             // consecutive turns per launch (> 1 only with gen_actions: the fused rollout driver)
     int32_t   lanes_per_wave;    // 64: 32 envs per wavefront; 32: 16 envs per wavefront + 32 helper lanes
     uint32_t  ablate;            // diagnostic: bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
 };

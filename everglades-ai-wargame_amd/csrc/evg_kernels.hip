@@ -101,11 +101,11 @@ __device__ __forceinline__ void store_obs_vec<int16_t>(int16_t* dst, const int (
 // random_actions stand-in for one (env, player): 7 distinct groups of 12 and 7 distinct nodes of 1..11
 // (agents/State_Machine/random_actions.py:38-46), partial Fisher-Yates on nibble-packed permutations.
 // Same contract as oracle/rng_spec.py random_action_rows.
-__device__ __forceinline__ void gen_random_rows(const DevState& S, uint32_t env_id, uint32_t episode, int turn, int p, int2 (&rows)[NA]) {
+__device__ __forceinline__ void gen_random_rows(uint32_t seed_lo, uint32_t seed_hi, uint32_t env_id, uint32_t episode, int turn, int p, int2 (&rows)[NA]) {
     uint32_t w[16];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_ACTION, (uint32_t)b, turn, 0, p, 0);
+        const uint4 x = rng_block(seed_lo, seed_hi, env_id, episode, RNG_ACTION, (uint32_t)b, turn, 0, p, 0);
         w[4 * b] = x.x; w[4 * b + 1] = x.y; w[4 * b + 2] = x.z; w[4 * b + 3] = x.w;
     }
     uint64_t gp = 0xBA9876543210ull;      // nibble i = i
@@ -132,21 +132,29 @@ __device__ __forceinline__ int xchg1(int v) { return __builtin_amdgcn_mov_dpp(v,
 // ---------------------------------------------------------------------------------------------
 // fused env-step: lane = (env slot, player); LPW / 2 envs per wavefront (LPW = 64 is the default variant)
 // ---------------------------------------------------------------------------------------------
-template <typename OT, int LPW>
-__global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
+// The kernel reads its arguments through the kernarg segment pointer instead of by-value parameters: in the multi-turn
+// instantiation that pointer is made opaque once per turn, so argument fields and table entries are (re)loaded next to
+// their uses by cheap scalar loads instead of staying live across the whole loop (which cost 60+ VGPRs in SGPR spills).
+struct StepArgs { DevState s_; StepIO io_; };
+typedef const StepArgs __attribute__((address_space(4))) * step_args_ptr;
+#define S (A->s_)
+#define io (A->io_)
+
+template <typename OT, int LPW, bool MULTI>
+__global__ void __launch_bounds__(WG) evg_step_kernel(StepArgs) {
+    step_args_ptr A = (step_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int EPW = LPW / 2;                        // envs per wavefront
     constexpr int DP_CAP = CombatLds<LPW>::DP_CAP;
     __shared__ StepLds<LPW> L;
     const int lane = threadIdx.x;
     const bool envlane = LPW == WG || lane < LPW;       // owns an env side; helper lanes only join the balanced phases
     const int E = envlane ? lane >> 1 : 0, P = lane & 1;
-    const int col = envlane ? lane : 0;                 // LDS column (helpers never write; their reads are discarded)
     const int e0 = blockIdx.x * EPW;
     const int nvalid = min(EPW, S.N - e0);
     const bool valid = envlane && E < nvalid;
     const int e = valid ? e0 + E : e0;
     const size_t N = (size_t)S.N;
-    const DevTables* __restrict__ T = S.T;
+    const DevTables* T = S.T;
 
     STAMP(0);
     // ---- constant tables: adjacency/defense to LDS (indexed per lane), the rest into scalar registers
@@ -154,12 +162,6 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         L.adj[lane] = T->adj_row[lane];
         L.defense[lane] = T->defense[lane];
     }
-    const uint64_t p1nib = T->p1map_nib;
-    const uint64_t spd_n = P ? T->speed_nib[1] : T->speed_nib[0];
-    const uint64_t ctl_n = P ? T->control_nib[1] : T->control_nib[0];
-    const uint64_t cst_n = P ? T->cost_nib[1] : T->cost_nib[0];
-    const uint64_t typ_n = P ? T->type_nib[1] : T->type_nib[0];
-    const int max_turns = T->max_turns;
 
     // ---- load state (env fastest; the two player rows of a group index interleave across lanes)
     const uint32_t envw = S.env[e];
@@ -178,11 +180,38 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
             if (n <= NN) L.NW[n][E] = S.node[(size_t)(n - 1) * N + e];
         }
     }
+    __syncthreads();
+    const bool observe_only = io.observe_only != 0;
+    const uint32_t abl = io.ablate;                     // diagnostic only (EVG_ABLATE); 0 in production
+
+    // One iteration = one turn.  evg_step runs exactly one; the fused rollout driver lets every wavefront play
+    // `turns` consecutive turns of its envs with the state resident in LDS/registers: outputs are still written every
+    // turn, but no wave waits for the slowest wave of the grid between turns, and nothing is re-loaded.
+    const int nturns = MULTI ? io.turns : 1;            // the single-turn instantiation has no loop at all
+    for (int iter = 0; iter < nturns; ++iter) {
+    // Multi-turn form: the argument pointer and the lane id are made opaque once per turn, so that argument fields, table
+    // entries and per-lane address arithmetic are recomputed next to their uses instead of being hoisted out of the loop
+    // and kept live across it (which overflowed the register file).  The declarations below shadow the prologue's.
+    int lane_ = threadIdx.x;
+    if (MULTI) { asm volatile("" : "+s"(A)); asm volatile("" : "+v"(lane_)); T = S.T; }
+    const int lane = lane_;
+    const bool envlane = LPW == WG || lane < LPW;
+    const int E = envlane ? lane >> 1 : 0, P = lane & 1;
+    const int col = envlane ? lane : 0;                 // LDS column (helpers never write; their reads are discarded)
+    const bool valid = envlane && E < nvalid;
+    const int e = valid ? e0 + E : e0;
+    const size_t N = (size_t)S.N;
+    const uint64_t p1nib = T->p1map_nib;
+    const uint64_t spd_n = P ? T->speed_nib[1] : T->speed_nib[0];
+    const uint64_t ctl_n = P ? T->control_nib[1] : T->control_nib[0];
+    const uint64_t cst_n = P ? T->cost_nib[1] : T->cost_nib[0];
+    const uint64_t typ_n = P ? T->type_nib[1] : T->type_nib[0];
+    const int max_turns = T->max_turns;
     // this player's 7 order rows: read from the caller's tensor (issued now, used after the barrier), or -- in the
     // fused random-vs-random rollout -- drawn here by the same generator as evg_random_actions and written out
     int2 act[NA];
     if (io.gen_actions) {
-        gen_random_rows(S, S.env_id_base + (uint32_t)e, episode, turn, P, act);
+        gen_random_rows(S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, turn, P, act);
         if (valid && io.actions_out) {
             int2* ao = reinterpret_cast<int2*>(io.actions_out) + ((size_t)e * 2 + P) * NA;
 #pragma unroll
@@ -193,13 +222,10 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) act[i] = io.actions ? ap[i] : make_int2(0, 0);
     }
-    __syncthreads();
     STAMP(1);
 
-    const bool observe_only = io.observe_only != 0;
     const bool frozen = status != 0;                    // finished, not auto-reset: repeat terminal outputs
     const bool play = valid && !frozen && !observe_only;
-    const uint32_t abl = io.ablate;                     // diagnostic only (EVG_ABLATE); 0 in production
 
     if (play) {
         turn += 1;                                                               // server.py:214
@@ -668,7 +694,8 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
     STAMP(10);
 
     // ---------------- store state (coalesced)
-    if (valid && !observe_only && (play || do_reset) && !(abl & 32u)) {
+    // (multi-turn form: the state lives on chip between turns and goes back to HBM after the launch's last turn)
+    if (valid && !observe_only && (MULTI ? iter == nturns - 1 : (play || do_reset)) && !(abl & 32u)) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) S.grp[(size_t)(P * 12 + k) * N + e] = gw[k];
 #pragma unroll
@@ -680,8 +707,12 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         }
         if (P == 0) {
             S.env[e] = (uint32_t)turn | ((uint32_t)status << 8);
-            if (do_reset) S.episode[e] = episode;
+            if (MULTI || do_reset) S.episode[e] = episode;
         }
+    }
+    if (MULTI && envlane) {                             // the next turn of this launch starts from these words
+#pragma unroll
+        for (int k = 0; k < 12; ++k) L.G[k][lane] = gw[k];
     }
     __syncthreads();        // output image complete; combat's health stores drained
     STAMP(11);
@@ -730,7 +761,12 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(DevState S, StepIO io) {
         for (int i = lane; i < NU; i += WG) dst[i] = make_double2(100.0, 100.0);
     }
     STAMP(13);
+    if (MULTI) __syncthreads();                         // this turn's health/output stores have left the wave before the next turn reads
+    }   // turns
 }
+
+#undef S
+#undef io
 
 // ---------------------------------------------------------------------------------------------
 // reset (everglades_env.py:75-116 -> server.py:133-209): masked, per env
@@ -780,7 +816,7 @@ __global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int
     const uint32_t episode = S.episode[e];
     const uint32_t env_id = S.env_id_base + (uint32_t)e;
     int2 rows[NA];
-    gen_random_rows(S, env_id, episode, turn, p, rows);
+    gen_random_rows(S.seed_lo, S.seed_hi, env_id, episode, turn, p, rows);
     int2* out = reinterpret_cast<int2*>(actions) + (size_t)idx * NA;
 #pragma unroll
     for (int i = 0; i < NA; ++i) out[i] = rows[i];
@@ -825,7 +861,7 @@ __global__ void __launch_bounds__(256) evg_scripted_actions_kernel(DevState S, i
             const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id, S.episode[e], RNG_DELAY, 0u, turn, 0, player, 0);
             go = (double)x.x / 4294967296.0 > 0.68;
         }
-        if (go) gen_random_rows(S, env_id, S.episode[e], turn, player, rows);
+        if (go) gen_random_rows(S.seed_lo, S.seed_hi, env_id, S.episode[e], turn, player, rows);
     } else if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50 || policy == EVG_POLICY_BASE_RUSH_V1 ||
                policy == EVG_POLICY_ALL_CYCLE) {
         // cycle_rush_turn25.py:62-115 (gate 25 / 50), base_rush_v1.py:62-96 (row i only while group i is not at node 11),
@@ -998,27 +1034,24 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 block(WG);
-    if (io.lanes_per_wave == 32) {
-        const dim3 grid((S.N + 15) / 16);
-        switch (obs_dtype) {
-            case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, 32>), grid, block, 0, s, S, io); break;
-            case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, 32>), grid, block, 0, s, S, io); break;
-            case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, 32>), grid, block, 0, s, S, io); break;
-            default: return -1;
-        }
-    } else {
-        const dim3 grid((S.N + 31) / 32);
-        switch (obs_dtype) {
-            case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, 64>), grid, block, 0, s, S, io); break;
-            case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, 64>), grid, block, 0, s, S, io); break;
-            case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, 64>), grid, block, 0, s, S, io); break;
-            default: return -1;
-        }
+template <int LPW, bool MULTI>
+static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
+    const dim3 grid((S.N + LPW / 2 - 1) / (LPW / 2)), block(WG);
+    const StepArgs args{S, io};
+    switch (obs_dtype) {
+        case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, LPW, MULTI>), grid, block, 0, s, args); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, LPW, MULTI>), grid, block, 0, s, args); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, LPW, MULTI>), grid, block, 0, s, args); break;
+        default: return -1;
     }
     return (int)hipGetLastError();
+}
+
+int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool multi = io.turns > 1;
+    if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
+    return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);
 }
 
 int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream) {

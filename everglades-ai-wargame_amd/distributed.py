@@ -21,10 +21,11 @@ def pack_episode_results(returns, length, winner):
                       length.to(torch.float32).reshape(-1, 1)], dim=1).contiguous()
 
 
-def gather_episode_results(returns, length, winner, total_envs=None, group=None):
+def gather_episode_results(returns, length, winner, total_envs=None, group=None, count_wins=True):
     """The single collective of the path.  Every rank passes the results of its own shard (tensors on its
     device); returns a dict with the results of ALL envs in global env order plus win counts
-    (p0, p1, tie, unfinished).  Works without an initialised process group (single GPU)."""
+    (p0, p1, tie, unfinished).  Works without an initialised process group (single GPU).  count_wins=False skips the
+    four host-synchronising reductions (`wins` is then None; call win_counts() on the result when needed)."""
     import torch
     import torch.distributed as dist
     local = pack_episode_results(returns, length, winner)
@@ -47,6 +48,13 @@ def gather_episode_results(returns, length, winner, total_envs=None, group=None)
         full = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).to(home)
     else:
         full = local
-    w = full[:, 2].to(torch.int64)
-    return dict(returns=full[:, :2], winner=w.to(torch.int8), length=full[:, 3].to(torch.int32),
-                wins=(int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum())))
+    out = dict(returns=full[:, :2], winner=full[:, 2].to(torch.int8), length=full[:, 3].to(torch.int32), wins=None)
+    if count_wins:
+        out["wins"] = win_counts(out)
+    return out
+
+
+def win_counts(gathered):
+    """(p0 wins, p1 wins, ties, envs without a finished episode) of a gather_episode_results() result."""
+    w = gathered["winner"].to("cpu")
+    return (int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum()))

@@ -201,13 +201,14 @@ class EvergladesVecEnv(object):
     def scripted_reset(self):
         _lib.check(self.L.evg_scripted_reset(self._h, self._stream()))
 
-    def rollout_random(self, steps, time_kernel=False, fused=True):
+    def rollout_random(self, steps, time_kernel=False, fused=True, turns_per_launch=1):
         """`steps` turns of random-vs-random play driven from native code (evg_rollout_random): per turn the
         on-device random_actions generator fills self._actions, then the step kernel runs (fused=True: the step kernel draws the same orders itself and stores them in
-        self._actions -- one launch per turn).  Returns the outputs of
+        self._actions -- one launch per turn; turns_per_launch > 1: persistent form, each launch plays that many
+        consecutive turns per wavefront, outputs still written every turn).  Returns the outputs of
         the last turn like step(); with time_kernel=True also the average step-kernel time in ms (synchronises)."""
         ms = C.c_float(0.0)
-        _lib.check(self.L.evg_rollout_random(self._h, int(steps), int(bool(fused)), self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
+        _lib.check(self.L.evg_rollout_random(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
                                              self._ptr(self.done), self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status),
                                              C.byref(ms) if time_kernel else None, self._stream()))
         out = (self.obs, self.reward, self.done, dict(winner=self.winner, scores=self.scores, status=self.status))

@@ -195,8 +195,11 @@ int evg_scripted_reset(evg_handle* h, void* stream);
 /* Rollout driver for random-vs-random play (the reference's demo/random_demo.py:90-113 loop with both
  * agents = random_actions): enqueues `steps` x (evg_random_actions into actions_buf, then evg_step) on
  * `stream` from native code, so that launch cost, not the Python interpreter, bounds small batches.
- * fused != 0: the step kernel draws the orders itself (same generator, same values) and stores them in
+ * fused == 1: the step kernel draws the orders itself (same generator, same values) and stores them in
  * actions_buf, which saves the second launch and the round trip of the action tensor through HBM.
+ * fused >= 2: additionally each launch plays up to `fused` consecutive turns per wavefront (persistent form: the
+ * state of a wavefront's envs stays in LDS/registers between turns; observations, rewards, actions ... are still
+ * written every turn, so the buffers hold the last turn as before).  Results are identical in all three forms.
  * Outputs as in evg_step (they hold the LAST step when the call returns).  If step_kernel_ms (host
  * pointer) is not NULL the step kernel of every 8th iteration is bracketed by hipEvents on `stream`, the
  * call synchronises the stream and stores the average of those step-kernel durations in milliseconds. */

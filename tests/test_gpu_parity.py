@@ -381,3 +381,26 @@ def test_smart_state_features_match_reference_fixture(evg):
             f = _np(env.smart_state(p, obs))
             assert np.array_equal(f, d["features"][:, p].astype(np.float32)), (dt, p)
         env.close()
+
+
+@pytest.mark.parametrize("tpl", [2, 7, 150])
+def test_persistent_multi_turn_rollout_equals_stepwise(evg, oracle_mod, tpl):
+    """The persistent rollout form (each launch plays `tpl` consecutive turns per wavefront with the state resident on
+    chip) gives exactly the results of one launch per turn and of the oracle -- across auto-resets, with a partial last
+    launch, and with the per-turn outputs holding the last turn."""
+    N, seed, steps = 500, 2024, 317
+    a = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    a.reset(); ora.reset()
+    out = a.rollout_random(steps, turns_per_launch=tpl)
+    for t in range(steps):
+        acts = ora.random_actions()
+        o_obs, o_rew, o_done, o_info = ora.step(acts)
+    assert np.array_equal(_np(out[0]).astype(np.float64), o_obs) and np.array_equal(_np(a._actions), acts)
+    assert np.array_equal(_np(out[3]["scores"]), o_info["scores"]) and np.array_equal(_np(out[2]), o_done)
+    assert np.allclose(_np(out[1]), o_rew, rtol=0, atol=REWARD_ATOL)
+    check_state(a, ora.get_state(), ("persistent", tpl))
+    sa, so = a.episode_stats(), ora.episode_stats()
+    assert np.array_equal(sa["totals"], so["totals"]) and np.array_equal(sa["winner"], so["winner"]) and np.array_equal(sa["length"], so["length"])
+    assert np.allclose(sa["returns"], so["returns"], rtol=1e-6, atol=1e-5)
+    a.close()
