@@ -44,17 +44,23 @@ def usable_cores():
     return n
 
 
-def pmc_traffic(n_local):
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
+def pmc_traffic(n_local, turns_per_launch):
+    """HBM bytes per TURN of the step kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md, calibrated in the same passes).
-    Counters cannot be read live from inside this process, so the newest committed figure for this config is
-    reported; None when there is none."""
+    Counters cannot be read live from inside this process, so the newest committed figure for this config and launch
+    form is reported; None when there is none."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     for f in reversed(files):
         try:
             d = json.load(open(f))
-            if int(d.get("envs", -1)) == n_local:
+            if int(d.get("envs", -1)) != n_local:
+                continue
+            forms = d.get("forms")
+            if forms:
+                form = forms["persistent"] if turns_per_launch > 1 else forms["one_launch_per_turn"]
+                return float(form["corrected_bytes_per_turn"]), os.path.relpath(f, ROOT)
+            if turns_per_launch == 1:
                 return float(d["corrected_bytes_per_launch"]), os.path.relpath(f, ROOT)
         except Exception:
             continue
@@ -198,7 +204,9 @@ def main():
         value = total * args.steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9
         st = env.episode_stats()
-        traffic, traffic_src = pmc_traffic(n_local)
+        tpl = args.turns_per_launch if args.workload == "random" else 1
+        traffic_turn, traffic_src = pmc_traffic(n_local, tpl)
+        traffic = traffic_turn * tpl if traffic_turn else None
         out = {
             "metric": "env-steps/sec at 65536 concurrent DemoMap games, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,8 +224,8 @@ def main():
                        "gathered_wins_all_ranks": list(evg.win_counts(gathered)) if gathered is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "achieved_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
-                         "measured_traffic_GBps": (traffic / (step_kernel_ms * 1e-3) / 1e9) if traffic else None,
+                         "achieved_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local * tpl, "turns_per_launch": tpl,
+                         "measured_traffic_GBps": (traffic_turn / (step_kernel_ms * 1e-3) / 1e9) if traffic_turn else None,
                          "note": "achieved uses the ALGORITHMIC bytes of SURVEY 8(d); it exceeds 1.0 of peak when the kernel moves fewer "
                                  "bytes than that accounting (health rows are only touched where combat hits): compare traffic",
                          "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms, "kernel_ms_is": "launch duration / turns played by the launch",
