@@ -14,16 +14,19 @@ import everglades_amd as evg
 NAMES = ["tables+state load", "orders", "combat0 snapshot", "combat1 worklist", "combatA draws", "combatB apply", "movement",
          "aggregates+capture", "rewards+stats+reset", "obs build", "state store", "obs write-out", "reset fill"]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+TPL = int(sys.argv[2]) if len(sys.argv) > 2 else 1       # turns per launch (stamps are those of the launch's last turn)
 env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True)
 env.reset()
 L = env.L
 L.evg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
-nb = (N + 31) // 32
+nb_buf = (N + 15) // 16          # the library sizes the buffer for the 16-env-per-wave variant
+nb = (N + 31) // 32              # workgroups of the default variant (32 envs per wave)
 for upto in (20, 80, 140):
     cur = int(env.get_state()["env"][0, 0])
-    env.rollout_random(upto - cur)
-    st = np.zeros((nb, 16), np.uint64)
+    env.rollout_random(upto - cur, turns_per_launch=TPL)
+    st = np.zeros((nb_buf, 16), np.uint64)
     assert L.evg_debug_read_stamps(env._h, st.ctypes.data_as(C.c_void_p)) == 0
+    st = st[:nb]
     d = np.diff(st[:, :14].astype(np.int64), axis=1)
     d = np.where(d < 0, 0, d)      # stamps inside the skipped combat block keep older values
     tot = (st[:, 13] - st[:, 0]).astype(np.int64)
