@@ -404,3 +404,26 @@ def test_persistent_multi_turn_rollout_equals_stepwise(evg, oracle_mod, tpl):
     assert np.array_equal(sa["totals"], so["totals"]) and np.array_equal(sa["winner"], so["winner"]) and np.array_equal(sa["length"], so["length"])
     assert np.allclose(sa["returns"], so["returns"], rtol=1e-6, atol=1e-5)
     a.close()
+
+
+def test_16_envs_per_wave_variant_matches_oracle(evg, oracle_mod, monkeypatch):
+    """EVG_LANES=32 selects the step-kernel variant with 16 envs per wavefront (32 helper lanes join the balanced
+    phases); slower on MI355X but kept as an option -- it must give the same results, single- and multi-turn."""
+    monkeypatch.setenv("EVG_LANES", "32")
+    N, seed, steps = 333, 31, 170
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    monkeypatch.delenv("EVG_LANES")
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset(); ora.reset()
+    for t in range(40):
+        a = env.random_actions()
+        obs, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(_np(a))
+        assert np.array_equal(_np(obs).astype(np.float64), o_obs), t
+    env.rollout_random(steps, turns_per_launch=50)
+    for t in range(steps):
+        o_obs, _, _, o_info = ora.step(ora.random_actions())
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs)
+    check_state(env, ora.get_state(), "lanes32")
+    assert np.array_equal(env.episode_stats()["totals"], ora.episode_stats()["totals"])
+    env.close()
