@@ -724,10 +724,7 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(StepArgs) {
         constexpr int NVEC = LPW * OBS / EP;
         const int limit = nvalid * OBS2;
         OT* out = reinterpret_cast<OT*>(io.obs) + (size_t)e0 * OBS2;
-#pragma unroll 4
-        for (int v = lane; v < NVEC; v += WG) {
-            const int elem0 = v * EP;
-            int vals[EP];
+        auto unpack = [&](int elem0, int (&vals)[EP]) {
             if constexpr (EP == 4) {
                 const uint2 raw = *reinterpret_cast<const uint2*>(&L.u.O[elem0]);
                 vals[0] = (int)(int16_t)(raw.x & 0xFFFFu); vals[1] = (int)(int16_t)(raw.x >> 16);
@@ -741,12 +738,37 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(StepArgs) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { vals[2 * j] = (int)(int16_t)(r4[j] & 0xFFFFu); vals[2 * j + 1] = (int)(int16_t)(r4[j] >> 16); }
             }
-            if (elem0 + EP <= limit) {
-                store_obs_vec<OT>(out + elem0, vals);
-            } else {
+        };
+        if (nvalid == EPW) {
+            // full workgroup (wave-uniform): straight-line batches of 8 LDS reads, then 8 convert + store, no bounds checks
+            constexpr int FULL = NVEC / WG, REM = NVEC % WG, BATCH = 8;
 #pragma unroll
-                for (int j = 0; j < EP; ++j)
-                    if (elem0 + j < limit) out[elem0 + j] = (OT)vals[j];
+            for (int b0 = 0; b0 < FULL; b0 += BATCH) {
+                int vals[BATCH][EP];
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j)
+                    if (b0 + j < FULL) unpack((lane + (b0 + j) * WG) * EP, vals[j]);
+#pragma unroll
+                for (int j = 0; j < BATCH; ++j)
+                    if (b0 + j < FULL) store_obs_vec<OT>(out + (lane + (b0 + j) * WG) * EP, vals[j]);
+            }
+            if (REM && lane < REM) {
+                int vals[EP];
+                unpack((lane + FULL * WG) * EP, vals);
+                store_obs_vec<OT>(out + (lane + FULL * WG) * EP, vals);
+            }
+        } else {
+            for (int v = lane; v < NVEC; v += WG) {            // last, partial workgroup of the grid
+                const int elem0 = v * EP;
+                int vals[EP];
+                unpack(elem0, vals);
+                if (elem0 + EP <= limit) {
+                    store_obs_vec<OT>(out + elem0, vals);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EP; ++j)
+                        if (elem0 + j < limit) out[elem0 + j] = (OT)vals[j];
+                }
             }
         }
     }
