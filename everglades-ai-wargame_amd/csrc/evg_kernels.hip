@@ -331,13 +331,16 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(StepArgs) {
         // Stage 1: wave-wide work list (one item per fighting group) and damage-pool layout, by prefix scan
         const int nfight = __popc(fmask);
         int incl = (ndw << 16) | nfight;                  // both counts in one scan: totals stay below 2^16 (<= 768 items, <= 2112 words)
-#pragma unroll
-        for (int d = 1; d < WG; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
+        // inclusive scan over the 64 lanes in registers: log-steps inside each row of 16 lanes (DPP row_shr, zero fill),
+        // then the row totals are carried across rows (DPP row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
         const int excl = incl - ((ndw << 16) | nfight);
-        const int tot = __shfl(incl, WG - 1), mid = __shfl(excl, LPW / 2);
+        const int tot = __builtin_amdgcn_readlane(incl, WG - 1), mid = __builtin_amdgcn_readlane(excl, LPW / 2);
         const int excl_i = excl & 0xFFFF, excl_d = excl >> 16, tot_i = tot & 0xFFFF, tot_d = tot >> 16, mid_i = mid & 0xFFFF, mid_d = mid >> 16;
         // the pool holds every fight of the wave in the common case; otherwise two passes of 16 envs each
         const int npass = tot_d <= DP_CAP ? 1 : 2;
