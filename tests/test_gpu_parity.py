@@ -218,6 +218,12 @@ def test_full_size_properties(evg, oracle_mod):
     assert st["totals"][0] == finished.sum() and st["totals"][1:].sum() == st["totals"][0]
     assert np.array_equal(st["winner"][lo:lo + n], ost["winner"]) and np.array_equal(st["length"][lo:lo + n], ost["length"])
     assert np.array_equal(s["health"][lo:lo + n], ora.get_state()["health"])
+    # Secondary, statistical check against the reference with its STOCK numpy entropy (SURVEY section 6/8c anchors over 200
+    # random-vs-random games: p0 108 / p1 91 / tie 1, 199 of 200 games last the full 150 turns): the keyed generator must
+    # not shift these rates.  With 65 536 games the binomial noise is 0.2 %, the anchor's own 95 % interval is +-7 %.
+    tot = st["totals"].astype(np.float64)
+    assert abs(tot[1] / tot[0] - 0.5) < 0.02 and tot[3] / tot[0] < 0.01
+    assert abs(tot[1] / tot[0] - 108 / 200) < 0.07 and (st["length"] == 150).mean() > 0.985
     env.close()
 
 
