@@ -82,7 +82,7 @@ def load():
     L.evg_move_table.restype = None
     L.evg_random_actions.argtypes = [vp, vp, vp]
     L.evg_rollout_random.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]
-    L.evg_rollout_policies.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]
+    L.evg_rollout_policies.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]
     L.evg_scripted_actions.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.evg_scripted_reset.argtypes = [vp, vp]
     L.evg_get_state.argtypes = [vp, vp, vp, vp, vp]

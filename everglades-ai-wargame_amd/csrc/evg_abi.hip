@@ -351,7 +351,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, nullptr, h->stamps, 1, h->lanes, h->ablate};
+    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, 0, 0, nullptr, h->stamps, 1, h->lanes, h->ablate};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -360,7 +360,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
 int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, 1, h->lanes, 0};
+    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr, nullptr, 1, h->lanes, 0};
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -423,12 +423,12 @@ int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf
                         status_out, step_kernel_ms, stream);
 }
 
-int evg_rollout_policies(evg_handle* h, int steps, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
+int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
                          uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
     if (policy0 < 0 || policy0 >= EVG_POLICY_COUNT || policy1 < 0 || policy1 >= EVG_POLICY_COUNT)
         return fail(EVG_ERR_INVALID, "policy out of range");
-    if (!obs_out) return fail(EVG_ERR_INVALID, "rollout_policies: obs_out is required (the agents read it)");
-    return rollout_impl(h, steps, 0, policy0, policy1, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out,
+    if (!obs_out && !fused) return fail(EVG_ERR_INVALID, "rollout_policies: obs_out is required (the agents read it)");
+    return rollout_impl(h, steps, fused, policy0, policy1, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out,
                         step_kernel_ms, stream);
 }
 
@@ -440,7 +440,8 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipStream_t s_ = s;
     const bool random_pair = policy0 == EVG_POLICY_RANDOM && policy1 == EVG_POLICY_RANDOM;
-    if (random_pair && fused >= 2) {
+    const int gen_mode = random_pair ? 1 : 2;          // what the step kernel draws itself when fused
+    if (fused >= 2) {
         // Persistent form: one launch plays up to `fused` consecutive turns per wavefront (state stays on chip, outputs are
         // written every turn).  step_kernel_ms then is the launch time divided by the turns it played.
         const int per_launch = fused;
@@ -450,7 +451,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
             HIP_TRY(hipEventCreate(&ev));
             h->events.push_back(ev);
         }
-        StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 1, actions_buf, h->stamps, 1, h->lanes, h->ablate};
+        StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, gen_mode, policy0, policy1, actions_buf, h->stamps, 1, h->lanes, h->ablate};
         int done_turns = 0;
         for (int l = 0; l < nlaunch; ++l) {
             io.turns = steps - done_turns < per_launch ? steps - done_turns : per_launch;
@@ -481,11 +482,13 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         HIP_TRY(hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, (fused && random_pair) ? 1 : 0, actions_buf, h->stamps, 1, h->lanes, h->ablate};
+    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? gen_mode : 0, policy0, policy1, actions_buf, h->stamps, 1, h->lanes, h->ablate};
     for (int i = 0; i < steps; ++i) {
         int rc = 0;
-        if (random_pair) {
-            if (!fused) rc = launch_random_actions(h->S, actions_buf, stream);
+        if (fused) {
+            // orders are drawn inside the step kernel
+        } else if (random_pair) {
+            rc = launch_random_actions(h->S, actions_buf, stream);
         } else {                                  // the agents read the observations of the previous turn from obs_out
             rc = launch_scripted_actions(h->S, policy0, 0, obs_out, actions_buf, h->cfg.obs_dtype, stream);
             if (!rc) rc = launch_scripted_actions(h->S, policy1, 1, obs_out, actions_buf, h->cfg.obs_dtype, stream);

@@ -89,7 +89,9 @@ struct StepIO {
     int32_t*  scores;
     uint8_t*  status;
     int32_t   observe_only;      // 1: only (re)build observations from the current state
-    int32_t   gen_actions;       // 1: draw both players' orders in the kernel (random_actions policy) instead of reading `actions`
+    int32_t   gen_actions;       // 1: draw both players' orders in the kernel (random_actions policy) instead of reading `actions`;
+                                 // 2: orders of the on-device scripted agents policy0 / policy1 (fused evg_rollout_policies)
+    int32_t   policy0, policy1;
     int32_t*  actions_out;       //    ... and store them here ([N][2][7][2], may be NULL)
     unsigned long long* stamps;  // diagnostic build (EVG_STAMPS) only, else NULL
     int32_t   turns;             // consecutive turns per launch (> 1 only with gen_actions: the fused rollout driver)

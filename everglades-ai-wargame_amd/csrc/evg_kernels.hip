@@ -132,6 +132,161 @@ __device__ __forceinline__ int xchg1(int v) { return __builtin_amdgcn_mov_dpp(v,
 // ---------------------------------------------------------------------------------------------
 // fused env-step: lane = (env slot, player); LPW / 2 envs per wavefront (LPW = 64 is the default variant)
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// scripted opponents (BASELINE config 5): all bots of agents/State_Machine/, one agent object per
+// (env, player) that lives across episodes like the reference's (evaluate.py:85-93).  The logic is written against a
+// small "view" of what the bots read from their observation (turn, own group locations in own numbering, own moving
+// flags, control state and opposing units of a board slot), so that the same code serves the standalone kernel (view =
+// the observation tensor) and the fused rollout (view = the on-chip state at the start of the turn, which is what the
+// observation of the previous turn was built from).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cycle_advance(int& group_num, int& node_num) {
+    group_num = (group_num + 1) % NG;
+    if (group_num == 0) node_num = node_num % NN + 1;
+}
+
+template <class View>
+__device__ __forceinline__ void agent_rows(int policy, const View& v, const DevTables* T, uint32_t seed_lo, uint32_t seed_hi, uint32_t env_id,
+                                           uint32_t episode, int player, bool commit, uint32_t* p_cycle, uint32_t* p_swarm, uint32_t* p_dfs, int2 (&rows)[NA]) {
+    // `commit` is false for the padding lanes of a partial last workgroup: they compute like everyone else but must not
+    // advance the agent state of the env their indices are clamped to
+    const int turn = v.turn();
+#pragma unroll
+    for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 0);                   // np.zeros(shape)
+    // cycling state shared by most bots: first_turn << 8 | group_num << 4 | node_num | strat_index << 9 | agentNumber==2 << 13
+    const uint32_t cst = *p_cycle;
+    int first = (int)((cst >> 8) & 1u), group_num = (int)((cst >> 4) & 15u), node_num = (int)(cst & 15u);
+    int strat = (int)((cst >> 9) & 15u), agent2 = (int)((cst >> 13) & 1u);
+    bool cyc_dirty = false;
+
+    if (policy == EVG_POLICY_RANDOM || policy == EVG_POLICY_RANDOM_DELAY) {
+        // random_actions.py:38-46, random_actions_2.py; random_actions_delay.py acts only when random.random() > 0.68
+        bool go = true;
+        if (policy == EVG_POLICY_RANDOM_DELAY) {
+            const uint4 x = rng_block(seed_lo, seed_hi, env_id, episode, RNG_DELAY, 0u, turn, 0, player, 0);
+            go = (double)x.x / 4294967296.0 > 0.68;
+        }
+        if (go) gen_random_rows(seed_lo, seed_hi, env_id, episode, turn, player, rows);
+    } else if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50 || policy == EVG_POLICY_BASE_RUSH_V1 ||
+               policy == EVG_POLICY_ALL_CYCLE) {
+        // cycle_rush_turn25.py:62-115 (gate 25 / 50), base_rush_v1.py:62-96 (row i only while group i is not at node 11),
+        // all_cycle.py (always)
+        const int gate = policy == EVG_POLICY_CYCLE_RUSH_25 ? 25 : 50;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int loc_i = v.loc(i);
+            bool issue = !first;
+            if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50) issue = issue && ((loc_i != 11 && turn > gate) || turn < gate);
+            if (policy == EVG_POLICY_BASE_RUSH_V1) issue = issue && loc_i != 11;
+            if (issue) { rows[i] = make_int2(group_num, node_num); cycle_advance(group_num, node_num); }
+        }
+        first = 0; cyc_dirty = true;
+    } else if (policy == EVG_POLICY_BULL_RUSH) {                           // bull_rush.py: all groups to 2, 2, 5, 5, 8, 8, 11, 11, ...
+        if (!first) {
+            if (strat == 8) strat = 0;
+            const int node = (int)((0xB852u >> (4 * (strat >> 1))) & 15u);   // node_strat = [2, 5, 8, 11]
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { rows[i] = make_int2(group_num, node); group_num = (group_num + 1) % NG; }
+            strat += 1;
+        }
+        first = 0; cyc_dirty = true;
+    } else if (policy >= EVG_POLICY_CYCLE_TARGET_NODE && policy <= EVG_POLICY_CYCLE_TARGET_NODE11P2) {
+        // cycle_target_node.py (target 11, level 75), ..._node1.py (1, 75), ..._node11.py (11, 500), ..._node11P2.py (11, +-500)
+        const int tar = policy == EVG_POLICY_CYCLE_TARGET_NODE1 ? 1 : 11, level = policy >= EVG_POLICY_CYCLE_TARGET_NODE11 ? 500 : 75;
+        if (first) {
+            if (policy == EVG_POLICY_CYCLE_TARGET_NODE11P2 && v.opp_units_slot(11) > 0) agent2 = 1;    // obs[44]
+        } else {
+            const int ctl = v.ctrl_slot(tar);                                                          // obs[tarNode * 4 - 1]
+            const bool controlled = (policy == EVG_POLICY_CYCLE_TARGET_NODE11P2 && agent2) ? ctl <= -level : ctl >= level;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (controlled) {
+                    rows[i] = make_int2(group_num, node_num);
+                    cycle_advance(group_num, node_num);
+                } else {
+                    const int cur = v.loc(group_num);
+                    const int nx = (int)(((tar == 1 ? T->tar_to_1 : T->tar_to_11) >> (4 * cur)) & 15ull);   // 15 encodes the bots' -1
+                    rows[i] = make_int2(group_num, nx == 15 ? -1 : nx);
+                    group_num = (group_num + 1) % NG;
+                }
+            }
+        }
+        first = 0; cyc_dirty = true;
+    } else if (policy == EVG_POLICY_DFS_ATTACK) {
+        // dfs_attack.py ignores the observation: its orders are an eventually periodic sequence of the call count,
+        // tabulated on the host at evg_create (including the rows that persist in its mutable default argument)
+        const uint32_t c = *p_dfs;
+        const uint32_t idx = c < (uint32_t)T->dfs_mu ? c : (uint32_t)T->dfs_mu + (c - (uint32_t)T->dfs_mu) % (uint32_t)T->dfs_lambda;
+        const uint64_t r = T->dfs_rows[idx];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rows[i] = make_int2((int)((r >> (8 * i)) & 15ull), (int)((r >> (8 * i + 4)) & 15ull));
+        if (commit) *p_dfs = c + 1u;
+    } else if (policy == EVG_POLICY_SAME_COMMANDS) {                        // same_commands.py / same_commands_2.py
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rows[i] = make_int2(i + 1, i + 1);
+    } else if (policy == EVG_POLICY_SWARM) {
+        uint32_t lst = *p_swarm;                                           // attack list, 8 nibbles
+        const uint4 x0 = rng_block(seed_lo, seed_hi, env_id, episode, RNG_SWARM, 0u, turn, 0, player, 0);
+        const uint4 x1 = rng_block(seed_lo, seed_hi, env_id, episode, RNG_SWARM, 1u, turn, 0, player, 0);
+        const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {                                      // i = 7 .. 1
+            const int i = 7 - k;
+            const int j = (int)__umulhi(w[k], (uint32_t)(i + 1));
+            const uint32_t x = ((lst >> (4 * i)) ^ (lst >> (4 * j))) & 15u;
+            lst ^= (x << (4 * i)) ^ (x << (4 * j));
+        }
+        if (commit) *p_swarm = lst;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 1);            // np.tile([0, 1], (7, 1))
+        const uint64_t mx = T->maxnbr_nib;
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = (int)((lst >> (4 * k)) & 15u);
+            const bool idle = v.moving(g) == 0;
+            const int pos = v.loc(g);
+            const int2 r = make_int2(g, (int)((mx >> (4 * pos)) & 15u));   // max(NODE_CONNECTIONS[pos]), :97
+#pragma unroll
+            for (int i = 0; i < NA; ++i) rows[i] = (idle && n == i) ? r : rows[i];
+            n += (idle && n < NA) ? 1 : 0;
+        }
+    }                                                                      // EVG_POLICY_NO_ACTION: zeros
+    if (cyc_dirty && commit)
+        *p_cycle = (uint32_t)node_num | ((uint32_t)group_num << 4) | ((uint32_t)first << 8) | ((uint32_t)strat << 9) | ((uint32_t)agent2 << 13);
+}
+
+// what a bot reads from its observation row (everglades_env.py:158-171 layout)
+template <typename OT>
+struct ObsView {
+    const OT* o;
+    __device__ int turn() const { return (int)o[0]; }
+    __device__ int loc(int k) const { return (int)o[45 + 5 * k]; }
+    __device__ int moving(int k) const { return (int)o[48 + 5 * k]; }
+    __device__ int ctrl_slot(int slot) const { return (int)o[4 * slot - 1]; }
+    __device__ int opp_units_slot(int slot) const { return (int)o[4 * slot]; }
+};
+
+// the same quantities taken from the on-chip state at the start of a turn (fused rollout)
+template <int LPW>
+struct ChipView {
+    const StepLds<LPW>* L;
+    int col, E, P, turn_;
+    uint64_t p1nib;
+    __device__ int node_of_slot(int slot) const { return P ? (int)((p1nib >> (4 * slot)) & 15u) : slot; }
+    __device__ int turn() const { return turn_; }
+    __device__ int loc(int k) const { const uint32_t l = L->G[k][col] & G_LOC_M; return P ? (int)((p1nib >> (4 * l)) & 15u) : (int)l; }
+    __device__ int moving(int k) const { return ((L->G[k][col] & G_MODE_M) >> G_MODE_S) == MODE_MOVING ? 1 : 0; }
+    __device__ int ctrl_slot(int slot) const { return (int)(L->NW[node_of_slot(slot)][E] & 0x3FFu) - 512; }
+    __device__ int opp_units_slot(int slot) const {                        // units of every non-destroyed opposing group listed at the node
+        const uint32_t n = (uint32_t)node_of_slot(slot);
+        int u = 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { const uint32_t w = L->G[k][col ^ 1]; u += (w & G_LOC_M) == n ? __popc(w & G_MASK_M) : 0; }
+        return u;
+    }
+};
+
 // The kernel reads its arguments through the kernarg segment pointer instead of by-value parameters: in the multi-turn
 // instantiation that pointer is made opaque once per turn, so argument fields and table entries are (re)loaded next to
 // their uses by cheap scalar loads instead of staying live across the whole loop (which cost 60+ VGPRs in SGPR spills).
@@ -141,7 +296,7 @@ typedef const StepArgs __attribute__((address_space(4))) * step_args_ptr;
 #define io (A->io_)
 
 template <typename OT, int LPW, bool MULTI>
-__global__ void __launch_bounds__(WG) evg_step_kernel(StepArgs) {
+__global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2))) evg_step_kernel(StepArgs) {
     step_args_ptr A = (step_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int EPW = LPW / 2;                        // envs per wavefront
     constexpr int DP_CAP = CombatLds<LPW>::DP_CAP;
@@ -211,7 +366,14 @@ __global__ void __launch_bounds__(WG) evg_step_kernel(StepArgs) {
     // fused random-vs-random rollout -- drawn here by the same generator as evg_random_actions and written out
     int2 act[NA];
     if (io.gen_actions) {
-        gen_random_rows(S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, turn, P, act);
+        if (io.gen_actions == 1) {
+            gen_random_rows(S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, turn, P, act);
+        } else {                                        // on-device scripted agents of both seats (evg_rollout_policies, fused)
+            const ChipView<LPW> view{&L, col, E, P, turn, p1nib};
+            const size_t ai = (size_t)P * N + e;
+            agent_rows(P ? io.policy1 : io.policy0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, valid,
+                       S.agent_cycle + ai, S.agent_swarm + ai, S.agent_dfs + ai, act);
+        }
         if (valid && io.actions_out) {
             int2* ao = reinterpret_cast<int2*>(io.actions_out) + ((size_t)e * 2 + P) * NA;
 #pragma unroll
@@ -847,134 +1009,17 @@ __global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int
     for (int i = 0; i < NA; ++i) out[i] = rows[i];
 }
 
-// ---------------------------------------------------------------------------------------------
-// scripted opponents (BASELINE config 5), one agent object per (env, player) that lives across
-// episodes like the reference's (evaluate.py:85-93):
-//   Cycle_BRush_Turn25 / Turn50   agents/State_Machine/cycle_rush_turn25.py:62-115 (constant 25 / 50)
-//   SwarmAgent                    agents/State_Machine/swarm_agent.py:66-102; np.random.shuffle of the
-//                                 module-global attack list -> keyed Fisher-Yates (oracle/rng_spec.py swarm_shuffle)
-// One thread per env; reads the player's observation row (turn, group locations, moving flags).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cycle_advance(int& group_num, int& node_num) {
-    group_num = (group_num + 1) % NG;
-    if (group_num == 0) node_num = node_num % NN + 1;
-}
-
+// standalone form of the scripted opponents: one thread per env, view = the observation tensor
 template <typename OT>
 __global__ void __launch_bounds__(256) evg_scripted_actions_kernel(DevState S, int policy, int player, const OT* obs, int32_t* actions) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= S.N) return;
-    const DevTables* __restrict__ T = S.T;
-    const OT* o = obs + ((size_t)e * 2 + player) * OBS;
-    int2* out = reinterpret_cast<int2*>(actions) + ((size_t)e * 2 + player) * NA;
     const size_t ai = (size_t)player * S.N + e;
-    const int turn = (int)o[0];
-    const uint32_t env_id = S.env_id_base + (uint32_t)e;
+    const ObsView<OT> v{obs + ((size_t)e * 2 + player) * OBS};
     int2 rows[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 0);                   // np.zeros(shape)
-    // cycling state shared by most bots: first_turn << 8 | group_num << 4 | node_num | strat_index << 9 | agentNumber==2 << 13
-    uint32_t cst = S.agent_cycle[ai];
-    int first = (int)((cst >> 8) & 1u), group_num = (int)((cst >> 4) & 15u), node_num = (int)(cst & 15u);
-    int strat = (int)((cst >> 9) & 15u), agent2 = (int)((cst >> 13) & 1u);
-    bool cyc_dirty = false;
-
-    if (policy == EVG_POLICY_RANDOM || policy == EVG_POLICY_RANDOM_DELAY) {
-        // random_actions.py:38-46, random_actions_2.py; random_actions_delay.py acts only when random.random() > 0.68
-        bool go = true;
-        if (policy == EVG_POLICY_RANDOM_DELAY) {
-            const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id, S.episode[e], RNG_DELAY, 0u, turn, 0, player, 0);
-            go = (double)x.x / 4294967296.0 > 0.68;
-        }
-        if (go) gen_random_rows(S.seed_lo, S.seed_hi, env_id, S.episode[e], turn, player, rows);
-    } else if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50 || policy == EVG_POLICY_BASE_RUSH_V1 ||
-               policy == EVG_POLICY_ALL_CYCLE) {
-        // cycle_rush_turn25.py:62-115 (gate 25 / 50), base_rush_v1.py:62-96 (row i only while group i is not at node 11),
-        // all_cycle.py (always)
-        const int gate = policy == EVG_POLICY_CYCLE_RUSH_25 ? 25 : 50;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int loc_i = (int)o[45 + 5 * i];
-            bool issue = !first;
-            if (policy == EVG_POLICY_CYCLE_RUSH_25 || policy == EVG_POLICY_CYCLE_RUSH_50) issue = issue && ((loc_i != 11 && turn > gate) || turn < gate);
-            if (policy == EVG_POLICY_BASE_RUSH_V1) issue = issue && loc_i != 11;
-            if (issue) { rows[i] = make_int2(group_num, node_num); cycle_advance(group_num, node_num); }
-        }
-        first = 0; cyc_dirty = true;
-    } else if (policy == EVG_POLICY_BULL_RUSH) {                           // bull_rush.py: all groups to 2, 2, 5, 5, 8, 8, 11, 11, ...
-        if (!first) {
-            if (strat == 8) strat = 0;
-            const int node = (int)((0xB852u >> (4 * (strat >> 1))) & 15u);   // node_strat = [2, 5, 8, 11]
-#pragma unroll
-            for (int i = 0; i < NA; ++i) { rows[i] = make_int2(group_num, node); group_num = (group_num + 1) % NG; }
-            strat += 1;
-        }
-        first = 0; cyc_dirty = true;
-    } else if (policy >= EVG_POLICY_CYCLE_TARGET_NODE && policy <= EVG_POLICY_CYCLE_TARGET_NODE11P2) {
-        // cycle_target_node.py (target 11, level 75), ..._node1.py (1, 75), ..._node11.py (11, 500), ..._node11P2.py (11, +-500)
-        const int tar = policy == EVG_POLICY_CYCLE_TARGET_NODE1 ? 1 : 11, level = policy >= EVG_POLICY_CYCLE_TARGET_NODE11 ? 500 : 75;
-        if (first) {
-            if (policy == EVG_POLICY_CYCLE_TARGET_NODE11P2 && (int)o[44] > 0) agent2 = 1;
-        } else {
-            const int ctl = (int)o[tar * 4 - 1];
-            const bool controlled = (policy == EVG_POLICY_CYCLE_TARGET_NODE11P2 && agent2) ? ctl <= -level : ctl >= level;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                if (controlled) {
-                    rows[i] = make_int2(group_num, node_num);
-                    cycle_advance(group_num, node_num);
-                } else {
-                    const int cur = (int)o[45 + 5 * group_num];
-                    const int nx = (int)(((tar == 1 ? T->tar_to_1 : T->tar_to_11) >> (4 * cur)) & 15ull);   // 15 encodes the bots' -1
-                    rows[i] = make_int2(group_num, nx == 15 ? -1 : nx);
-                    group_num = (group_num + 1) % NG;
-                }
-            }
-        }
-        first = 0; cyc_dirty = true;
-    } else if (policy == EVG_POLICY_DFS_ATTACK) {
-        // dfs_attack.py ignores the observation: its orders are an eventually periodic sequence of the call count,
-        // tabulated on the host at evg_create (including the rows that persist in its mutable default argument)
-        const uint32_t c = S.agent_dfs[ai];
-        const uint32_t idx = c < (uint32_t)T->dfs_mu ? c : (uint32_t)T->dfs_mu + (c - (uint32_t)T->dfs_mu) % (uint32_t)T->dfs_lambda;
-        const uint64_t r = T->dfs_rows[idx];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) rows[i] = make_int2((int)((r >> (8 * i)) & 15ull), (int)((r >> (8 * i + 4)) & 15ull));
-        S.agent_dfs[ai] = c + 1u;
-    } else if (policy == EVG_POLICY_SAME_COMMANDS) {                        // same_commands.py / same_commands_2.py
-#pragma unroll
-        for (int i = 0; i < NA; ++i) rows[i] = make_int2(i + 1, i + 1);
-    } else if (policy == EVG_POLICY_SWARM) {
-        uint32_t lst = S.agent_swarm[ai];                                  // attack list, 8 nibbles
-        const uint32_t episode = S.episode[e];
-        const uint4 x0 = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_SWARM, 0u, turn, 0, player, 0);
-        const uint4 x1 = rng_block(S.seed_lo, S.seed_hi, env_id, episode, RNG_SWARM, 1u, turn, 0, player, 0);
-        const uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {                                      // i = 7 .. 1
-            const int i = 7 - k;
-            const int j = (int)__umulhi(w[k], (uint32_t)(i + 1));
-            const uint32_t x = ((lst >> (4 * i)) ^ (lst >> (4 * j))) & 15u;
-            lst ^= (x << (4 * i)) ^ (x << (4 * j));
-        }
-        S.agent_swarm[ai] = lst;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 1);            // np.tile([0, 1], (7, 1))
-        const uint64_t mx = T->maxnbr_nib;
-        int n = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int g = (int)((lst >> (4 * k)) & 15u);
-            const bool idle = (int)o[48 + 5 * g] == 0;
-            const int pos = (int)o[45 + 5 * g];
-            const int2 r = make_int2(g, (int)((mx >> (4 * pos)) & 15u));   // max(NODE_CONNECTIONS[pos]), :97
-#pragma unroll
-            for (int i = 0; i < NA; ++i) rows[i] = (idle && n == i) ? r : rows[i];
-            n += (idle && n < NA) ? 1 : 0;
-        }
-    }                                                                      // EVG_POLICY_NO_ACTION: zeros
-    if (cyc_dirty)
-        S.agent_cycle[ai] = (uint32_t)node_num | ((uint32_t)group_num << 4) | ((uint32_t)first << 8) | ((uint32_t)strat << 9) | ((uint32_t)agent2 << 13);
+    agent_rows(policy, v, S.T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, S.episode[e], player, true, S.agent_cycle + ai, S.agent_swarm + ai,
+               S.agent_dfs + ai, rows);
+    int2* out = reinterpret_cast<int2*>(actions) + ((size_t)e * 2 + player) * NA;
 #pragma unroll
     for (int i = 0; i < NA; ++i) out[i] = rows[i];
 }

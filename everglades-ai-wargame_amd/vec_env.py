@@ -214,13 +214,15 @@ class EvergladesVecEnv(object):
         out = (self.obs, self.reward, self.done, dict(winner=self.winner, scores=self.scores, status=self.status))
         return out + (float(ms.value),) if time_kernel else out
 
-    def rollout_policies(self, steps, policy0, policy1, time_kernel=False):
+    def rollout_policies(self, steps, policy0, policy1, time_kernel=False, fused=True, turns_per_launch=1):
         """`steps` turns of on-device policy0 (seat 0) vs policy1 (seat 1), driven from native code (evg_rollout_policies).
-        self.obs must hold the current observations (it does after reset()/step())."""
+        fused=False: two agent launches per turn read self.obs (which must hold the current observations; it does after
+        reset()/step()); fused=True: the step kernel evaluates both agents from the on-chip state, one launch per turn or --
+        turns_per_launch > 1 -- the persistent form.  Identical results."""
         ms = C.c_float(0.0)
         p0 = self.POLICIES[policy0] if isinstance(policy0, str) else int(policy0)
         p1 = self.POLICIES[policy1] if isinstance(policy1, str) else int(policy1)
-        _lib.check(self.L.evg_rollout_policies(self._h, int(steps), p0, p1, self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
+        _lib.check(self.L.evg_rollout_policies(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p0, p1, self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
                                                self._ptr(self.done), self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status),
                                                C.byref(ms) if time_kernel else None, self._stream()))
         out = (self.obs, self.reward, self.done, self._info)

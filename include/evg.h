@@ -207,10 +207,12 @@ int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf
                        uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
                        float* step_kernel_ms, void* stream);
 
-/* The same driver for any pair of on-device policies (EVG_POLICY_*; BASELINE config 5 is CYCLE_RUSH_25 vs SWARM): per
- * turn two agent launches read the previous observations in obs_out (which must hold the current observations when
- * the call starts, e.g. from evg_reset) and one step launch follows. */
-int evg_rollout_policies(evg_handle* h, int steps, int policy0, int policy1, int32_t* actions_buf, void* obs_out,
+/* The same driver for any pair of on-device policies (EVG_POLICY_*; BASELINE config 5 is CYCLE_RUSH_25 vs SWARM).
+ * fused == 0: per turn two agent launches read the previous observations in obs_out (which must hold the current
+ * observations when the call starts, e.g. from evg_reset) and one step launch follows.  fused == 1: the step kernel
+ * evaluates both agents itself from the on-chip state (the same quantities their observation holds) and stores the
+ * orders in actions_buf; fused >= 2: persistent form as in evg_rollout_random.  Identical results in all forms. */
+int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out,
                          float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
                          float* step_kernel_ms, void* stream);
 

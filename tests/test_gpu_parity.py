@@ -333,21 +333,32 @@ def test_turn_can_be_captured_in_a_hip_graph(evg, oracle_mod):
     env.close()
 
 
-def test_native_policy_rollout_equals_stepwise(evg):
+@pytest.mark.parametrize("seats", [("cycle_rush_turn25", "swarm"), ("cycle_target_node11P2", "dfs_attack"), ("random_actions_delay", "base_rush_v1"),
+                                   ("swarm", "cycle_target_node1"), ("bull_rush", "all_cycle")])
+def test_native_policy_rollout_forms_agree(evg, seats):
+    """evg_rollout_policies: agents as separate launches reading the observation tensor == agents fused into the step
+    kernel reading the on-chip state (one launch per turn, and the persistent form) == stepping by hand."""
     N, seed, steps = 300, 12, 200
-    a = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
-    b = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
-    a.reset(); b.reset()
-    a.rollout_policies(steps, "cycle_rush_turn25", "swarm")
+    envs = [evg.EvergladesVecEnv(N, seed=seed, auto_reset=True) for _ in range(4)]
+    for e in envs:
+        e.reset()
+    envs[0].rollout_policies(steps, seats[0], seats[1], fused=False)
+    envs[1].rollout_policies(steps, seats[0], seats[1], fused=True)
+    envs[2].rollout_policies(steps, seats[0], seats[1], fused=True, turns_per_launch=37)
     for t in range(steps):
-        b.scripted_actions("cycle_rush_turn25", 0)
-        b.step(b.scripted_actions("swarm", 1))
-    assert np.array_equal(_np(a.obs), _np(b.obs)) and np.array_equal(_np(a._actions), _np(b._actions))
-    sa, sb = a.get_state(), b.get_state()
-    for k in sa:
-        assert np.array_equal(sa[k], sb[k]), k
-    assert np.array_equal(a.episode_stats()["totals"], b.episode_stats()["totals"]) and a.episode_stats()["totals"][0] > N
-    a.close(); b.close()
+        envs[3].scripted_actions(seats[0], 0)
+        envs[3].step(envs[3].scripted_actions(seats[1], 1))
+    ref = envs[3]
+    sr = ref.get_state()
+    for i, e in enumerate(envs[:3]):
+        assert np.array_equal(_np(e.obs), _np(ref.obs)) and np.array_equal(_np(e._actions), _np(ref._actions)), (seats, i)
+        se = e.get_state()
+        for k in sr:
+            assert np.array_equal(se[k], sr[k]), (seats, i, k)
+        assert np.array_equal(e.episode_stats()["totals"], ref.episode_stats()["totals"])
+    assert ref.episode_stats()["totals"][0] > 0
+    for e in envs:
+        e.close()
 
 
 @pytest.mark.parametrize("pol", list(range(15)))
