@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--obs-dtype", default="float32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--turns-per-launch", type=int, default=150,
-                    help="random workload: consecutive turns each wavefront plays per launch of the step kernel (persistent rollout form; "
+                    help="consecutive turns each wavefront plays per launch of the step kernel (persistent rollout form; "
                          "1 = one launch per turn). Outputs are written every turn in both forms and the results are identical.")
     ap.add_argument("--workload", default="random", choices=["random", "scripted"],
                     help="random: BASELINE metric config (random vs random); scripted: BASELINE config 5 (cycle_rush_turn25 vs swarm)")
@@ -155,18 +155,18 @@ def main():
         torch.cuda.synchronize(device)
 
     def run(nsteps, timed, tpl=None):
+        """nsteps turns through the native rollout driver (evg_rollout_random / evg_rollout_policies: launches of the step
+        kernel with the agents of both seats fused in, enqueued from C on torch's current stream), split at multiples of 150
+        turns (the episode length of random vs random) where the episode results are gathered.  Returns the summed
+        step-kernel time in ms (HIP events recorded on that stream around the step-kernel launches) and the last gather."""
         tpl = args.turns_per_launch if tpl is None else tpl
-        """nsteps turns through the native rollout driver (evg_rollout_random: per turn the random_actions kernel then
-        the step kernel, enqueued from C on torch's current stream), split at episode boundaries (every 150 turns for
-        random vs random) where the episode results are gathered.  Returns the summed step-kernel time in ms (HIP
-        events recorded on that stream around every step-kernel launch) and the last gather."""
         nonlocal turn_counter
         kernel_ms_sum, gathered = 0.0, None
         left = nsteps
         while left > 0:
             chunk = min(left, period - turn_counter % period)
             out = (env.rollout_random(chunk, time_kernel=timed, turns_per_launch=tpl) if args.workload == "random" else
-                   env.rollout_policies(chunk, "cycle_rush_turn25", "swarm", time_kernel=timed))
+                   env.rollout_policies(chunk, "cycle_rush_turn25", "swarm", time_kernel=timed, fused=True, turns_per_launch=tpl))
             if timed:
                 kernel_ms_sum += out[-1] * chunk
             turn_counter += chunk
@@ -192,7 +192,7 @@ def main():
 
     # for reference, outside the timed region: the same rollout with one launch per turn (what env.step() costs per call)
     per_turn_launch = None
-    if args.workload == "random" and args.turns_per_launch > 1 and world == 1:
+    if args.turns_per_launch > 1 and world == 1:
         barrier()
         t1 = time.perf_counter()
         k1, _ = run(150, True, tpl=1)
@@ -204,8 +204,9 @@ def main():
         value = total * args.steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9
         st = env.episode_stats()
-        tpl = args.turns_per_launch if args.workload == "random" else 1
-        traffic_turn, traffic_src = pmc_traffic(n_local, tpl)
+        tpl = args.turns_per_launch
+        # the committed PMC passes are of the random-vs-random workload
+        traffic_turn, traffic_src = pmc_traffic(n_local, tpl) if args.workload == "random" else (None, None)
         traffic = traffic_turn * tpl if traffic_turn else None
         out = {
             "metric": "env-steps/sec at 65536 concurrent DemoMap games, 1/2/4/8 MI355X",
@@ -214,10 +215,10 @@ def main():
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": ("%d concurrent DemoMap games per GPU, random_actions vs random_actions drawn on device (fused into the "
                                     "step kernel, orders written to an [N,2,7,2] tensor; persistent rollout form, see turns_per_launch), auto-reset, obs %s [N,2,105]" if args.workload == "random" else
-                                    "%d concurrent DemoMap games per GPU, on-device Cycle_BRush_Turn25 vs SwarmAgent (BASELINE config 5; episodes end by "
-                                    "BaseCapture after 84-94 turns), auto-reset, obs %s [N,2,105]") % (n_local, args.obs_dtype),
+                                    "%d concurrent DemoMap games per GPU, on-device Cycle_BRush_Turn25 vs SwarmAgent (BASELINE config 5; both bots fused into the "
+                                    "step kernel, orders written out; episodes end by BaseCapture after 84-94 turns), auto-reset, obs %s [N,2,105]") % (n_local, args.obs_dtype),
                        "envs_per_gpu": n_local, "total_envs": total,
-                       "turns_per_launch": args.turns_per_launch if args.workload == "random" else 1,
+                       "turns_per_launch": args.turns_per_launch,
                        "one_launch_per_turn": per_turn_launch, "parallelism": "env-sharded x%d" % world,
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
