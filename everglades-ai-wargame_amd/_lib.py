@@ -12,14 +12,15 @@ LIB_PATH = os.environ.get("EVG_LIB_PATH") or os.path.join(HERE, "libevg.so")   #
 NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105
 MAX_SCORE = 3700
 OBS_F32, OBS_F64, OBS_I16 = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
+RNG_KEYED_PHILOX, RNG_STOCK_MT19937 = 0, 1
 POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "all_cycle", "base_rush_v1", "bull_rush",
                 "cycle_target_node", "cycle_target_node1", "cycle_target_node11", "cycle_target_node11P2", "dfs_attack", "no_action",
                 "random_actions_delay", "same_commands"]      # index = EVG_POLICY_* of include/evg.h (agents/State_Machine/<name>.py)
 POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
 EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_fog_of_war", "evg_smart_state", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
-           "evg_get_state", "evg_set_state", "evg_episode_stats", "evg_episode_stats_device", "evg_num_envs",
+           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
 
@@ -38,7 +39,7 @@ class EvgConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int32), ("device_id", C.c_int32),
         ("seed", C.c_uint64), ("env_id_base", C.c_uint64), ("obs_dtype", C.c_int32), ("auto_reset", C.c_int32),
-        ("tables", EvgTables),
+        ("rng_mode", C.c_int32), ("reserved0", C.c_int32), ("tables", EvgTables),
     ]
 
 
@@ -87,6 +88,9 @@ def load():
     L.evg_scripted_reset.argtypes = [vp, vp]
     L.evg_get_state.argtypes = [vp, vp, vp, vp, vp]
     L.evg_set_state.argtypes = [vp, vp, vp, vp, vp]
+    L.evg_seed_stock_entropy.argtypes = [vp, vp, vp]
+    L.evg_get_stock_entropy.argtypes = [vp, vp]
+    L.evg_set_stock_entropy.argtypes = [vp, vp]
     L.evg_episode_stats.argtypes = [vp, vp, vp, vp, vp]
     L.evg_episode_stats_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.evg_num_envs.argtypes = [vp]

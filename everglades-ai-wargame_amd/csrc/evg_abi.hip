@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "evg_device.h"
+#include "evg_mt.h"
 
 using namespace evg;
 
@@ -260,6 +261,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
                     sizeof(evg_config), EVG_ABI_VERSION);
     if (cfg->num_envs < 1) return fail(EVG_ERR_INVALID, "num_envs must be >= 1");
     if (cfg->obs_dtype < EVG_OBS_F32 || cfg->obs_dtype > EVG_OBS_I16) return fail(EVG_ERR_INVALID, "obs_dtype");
+    if (cfg->rng_mode != EVG_RNG_KEYED_PHILOX && cfg->rng_mode != EVG_RNG_STOCK_MT19937) return fail(EVG_ERR_INVALID, "rng_mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(EVG_ERR_NO_DEVICE, "no HIP device visible; libevg has no CPU path");
@@ -299,6 +301,11 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (!rc) rc = dev_alloc(h, &S.agent_swarm, 2 * N);
     if (!rc) rc = dev_alloc(h, &S.agent_dfs, 2 * N);
     if (!rc) rc = dev_alloc(h, &h->d_tables, 1);
+    uint32_t *mt_key = nullptr, *mt_pos = nullptr;       // attached to S after the create-time reset, which must not draw
+    if (!rc && cfg->rng_mode == EVG_RNG_STOCK_MT19937) {
+        rc = dev_alloc(h, &mt_key, (size_t)MT_N * N);
+        if (!rc) rc = dev_alloc(h, &mt_pos, N);
+    }
     if (rc) { evg_destroy(h); return rc; }
     S.T = h->d_tables;
 #ifdef EVG_STAMPS
@@ -315,6 +322,10 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     // first evg_reset opens episode 0
     if (e == hipSuccess && launch_reset(S, nullptr, nullptr, cfg->obs_dtype, nullptr) != 0) e = hipGetLastError();
     if (e == hipSuccess && launch_scripted_reset(S, nullptr) != 0) e = hipGetLastError();
+    if (e == hipSuccess && mt_key) {
+        S.mt_key = mt_key; S.mt_pos = mt_pos;
+        if (launch_mt_seed(S, nullptr, nullptr) != 0) e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemset(S.episode, 0xFF, N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -441,6 +452,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
     hipStream_t s_ = s;
     const bool random_pair = policy0 == EVG_POLICY_RANDOM && policy1 == EVG_POLICY_RANDOM;
     const int gen_mode = random_pair ? 1 : 2;          // what the step kernel draws itself when fused
+    if (h->S.mt_key && fused > 1) fused = 1;           // stock-entropy mode: single-turn launches only
     if (fused >= 2) {
         // Persistent form: one launch plays up to `fused` consecutive turns per wavefront (state stays on chip, outputs are
         // written every turn).  step_kernel_ms then is the launch time divided by the turns it played.
@@ -510,6 +522,55 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         }
         *step_kernel_ms = (float)(tot / nsamples);
     }
+    return EVG_OK;
+}
+
+int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const uint32_t* d_seeds = nullptr;
+    if (seeds) {                                        // staged in the (about to be overwritten) key array itself: row 623 is written last
+        uint32_t* stage = h->S.mt_key + (size_t)(MT_N - 1) * h->S.N;
+        HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+        HIP_TRY(hipMemcpy(stage, seeds, (size_t)h->S.N * sizeof(uint32_t), hipMemcpyHostToDevice));
+        d_seeds = stage;
+    }
+    const int rc = launch_mt_seed(h->S, d_seeds, stream);
+    if (rc) return fail(EVG_ERR_HIP, "seed launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_get_stock_entropy(evg_handle* h, uint32_t* out) {
+    if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
+    if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t)h->S.N;
+    std::vector<uint32_t> k((size_t)MT_N * N), pos(N);
+    HIP_TRY(hipMemcpy(k.data(), h->S.mt_key, k.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos.data(), h->S.mt_pos, N * 4, hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < N; ++e) {
+        for (int i = 0; i < MT_N; ++i) out[e * (MT_N + 1) + i] = k[(size_t)i * N + e];
+        out[e * (MT_N + 1) + MT_N] = pos[e];
+    }
+    return EVG_OK;
+}
+
+int evg_set_stock_entropy(evg_handle* h, const uint32_t* in) {
+    if (!h || !in) return fail(EVG_ERR_INVALID, "null argument");
+    if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t)h->S.N;
+    std::vector<uint32_t> k((size_t)MT_N * N), pos(N);
+    for (size_t e = 0; e < N; ++e) {
+        for (int i = 0; i < MT_N; ++i) k[(size_t)i * N + e] = in[e * (MT_N + 1) + i];
+        pos[e] = in[e * (MT_N + 1) + MT_N];
+        if (pos[e] > (uint32_t)MT_N) return fail(EVG_ERR_INVALID, "env %zu: generator position %u > 624", e, pos[e]);
+    }
+    HIP_TRY(hipMemcpy(h->S.mt_key, k.data(), k.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->S.mt_pos, pos.data(), N * 4, hipMemcpyHostToDevice));
     return EVG_OK;
 }
 

@@ -18,6 +18,7 @@
 //   health f64 [N][200]  env-major: unitHealth of player p group k at [p*100 + 8k ...]; a group's
 //                         row is one 64-byte (96 for group 11) aligned segment, touched only by combat
 //   ep_ret f32 [2][N], fin_ret f32 [N][2], fin_len i32 [N], fin_win i8 [N], totals u64[4]
+//   mt_key u32 [624][N], mt_pos u32 [N]   per-env MT19937 of the stock-entropy mode (rng_mode 1) only
 #pragma once
 #include <stdint.h>
 #include "../../include/evg.h"
@@ -76,6 +77,8 @@ struct DevState {
     uint32_t* agent_cycle;       // [2][N] scripted-agent state: first_turn << 8 | group_num << 4 | node_num
     uint32_t* agent_swarm;       // [2][N] SwarmAgent attack list, 8 nibbles
     uint32_t* agent_dfs;         // [2][N] dfs_attack call counter
+    uint32_t* mt_key;            // [624][N] stock-entropy mode only (evg_mt.h), else NULL
+    uint32_t* mt_pos;            // [N]
     uint32_t  seed_lo, seed_hi, env_id_base;
     const DevTables* T;
 };
@@ -106,6 +109,7 @@ int launch_random_actions(const DevState& S, int32_t* actions, void* stream);
 int launch_scripted_actions(const DevState& S, int policy, int player, const void* obs, int32_t* actions, int obs_dtype, void* stream);
 int launch_scripted_reset(const DevState& S, void* stream);
 int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, void* stream);
+int launch_mt_seed(const DevState& S, const uint32_t* seeds_dev, void* stream);
 int launch_smart_state(const DevState& S, int player, const void* obs, float* out, int obs_dtype, void* stream);
 
 }  // namespace evg

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include "evg_device.h"
 #include "evg_rng.h"
+#include "evg_mt.h"
 
 namespace evg {
 
@@ -295,8 +296,9 @@ typedef const StepArgs __attribute__((address_space(4))) * step_args_ptr;
 #define S (A->s_)
 #define io (A->io_)
 
-template <typename OT, int LPW, bool MULTI>
+template <typename OT, int LPW, bool MULTI, bool MT = false>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2))) evg_step_kernel(StepArgs) {
+    static_assert(!MT || (!MULTI && LPW == WG), "the stock-entropy mode exists in the single-turn, 32-envs-per-wave form only");
     step_args_ptr A = (step_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int EPW = LPW / 2;                        // envs per wavefront
     constexpr int DP_CAP = CombatLds<LPW>::DP_CAP;
@@ -338,6 +340,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __syncthreads();
     const bool observe_only = io.observe_only != 0;
     const uint32_t abl = io.ablate;                     // diagnostic only (EVG_ABLATE); 0 in production
+    // stock-entropy mode: the env's MT19937 is advanced by the lane of player 0, in the reference's draw order
+    MtGen mt{nullptr, 0, 0};
+    const bool mt_lane = MT && valid && P == 0;
+    if (MT && mt_lane) { mt.key = S.mt_key + e; mt.stride = N; mt.pos = S.mt_pos[e]; }
 
     // One iteration = one turn.  evg_step runs exactly one; the fused rollout driver lets every wavefront play
     // `turns` consecutive turns of its envs with the state resident in LDS/registers: outputs are still written every
@@ -558,6 +564,41 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // Phase A (:549-566): one lane per fighting group; each of its alive units draws one target among the
             // opposing side's alive fighting units at the node; damage accumulates in the pool (LDS atomics,
             // integer and order-free, hence deterministic)
+            if constexpr (MT) {
+                // stock entropy: one sequential stream per env, consumed exactly in the reference's loop order -- nodes
+                // ascending (:505), attacking player 0 then 1 (:549), that player's groups in list order (ascending
+                // `base`), one draw per alive unit (:562)
+                if (mt_lane && inpass) {
+                    uint32_t c = contested;
+                    while (c) {
+                        const int node = __ffs(c) - 1;
+                        c &= c - 1;
+                        for (int side = 0; side < 2; ++side) {
+                            const int SL = lane | side;
+                            const uint32_t fso = L.u.c.FS[node][SL ^ 1];
+                            const uint32_t tot_o = fso >> 16, doff_o = fso & 0xFFFFu;
+                            const uint64_t tn_s = side ? T->type_nib[1] : T->type_nib[0];
+                            int last = -1;
+                            for (;;) {
+                                int best = 256, bg = -1, bcnt = 0;
+                                for (int k = 0; k < 12; ++k) {
+                                    const uint32_t sp = L.u.c.SNAP[k][SL];
+                                    const int b = (int)((sp >> 16) & 0xFFu);
+                                    if ((sp >> 31) && (int)((sp >> 12) & 15u) == node && b > last && b < best) { best = b; bg = k; bcnt = __popc(sp & 0xFFFu); }
+                                }
+                                if (bg < 0) break;
+                                last = best;
+                                const uint32_t type = (uint32_t)((tn_s >> (4 * bg)) & 15u);
+                                const uint32_t dmg = (dmg_nib >> (4 * type)) & 15u;
+                                for (int j = 0; j < bcnt; ++j) {
+                                    const uint32_t uid = mt_randint(mt, tot_o);
+                                    atomicAdd(&L.u.c.DP[doff_o + (uid >> 2)], dmg << (8 * (uid & 3u)));
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
             for (int it = lane; it < nitems; it += WG) {
                 const uint32_t item = L.u.c.W[it];
                 const int SL = (int)(item & 63u), gid = (int)(item >> 6), side = SL & 1;
@@ -581,6 +622,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         }
                     }
                 }
+            }
             }
             __syncthreads();
             STAMP(5);
@@ -753,6 +795,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (turn >= max_turns) status = EVG_TIME_EXPIRED;                          // :321
         else if (my_alive + opp_alive == 0) status = EVG_ANNIHILATION;             // :324
         else if (base_cap) status = EVG_BASE_CAPTURE;                              // :327
+        if (MT && mt_lane && turn % 10 == 0) (void)mt_randint(mt, 2u * NG + 1u);    // :337-338 focus draw: unobservable, but it consumes output
     }
     STAMP(8);
 
@@ -804,6 +847,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (do_reset) {
         // new episode: state of game_init (server.py:133-209)
         turn = 0; status = 0; episode += 1u;
+        if (MT && mt_lane) { (void)mt_randint(mt, 2u * NG + 1u); (void)mt_randint(mt, 2u * NG + 1u); }   // game_init :205 and its game_end :338 (turn 0)
 #pragma unroll
         for (int j = 0; j < 3; ++j) st[j] = 0;
 #pragma unroll
@@ -873,6 +917,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (P == 0) {
             S.env[e] = (uint32_t)turn | ((uint32_t)status << 8);
             if (MULTI || do_reset) S.episode[e] = episode;
+            if (MT) S.mt_pos[e] = mt.pos;
         }
     }
     if (MULTI && envlane) {                             // the next turn of this launch starts from these words
@@ -977,6 +1022,12 @@ __global__ void __launch_bounds__(WG) evg_reset_kernel(DevState S, const uint8_t
         S.episode[e] += 1u;                 // 0xFFFFFFFF at create -> episode 0 on the first reset
         S.ep_ret[e] = 0.f;
         S.ep_ret[N + e] = 0.f;
+        if (S.mt_key) {                     // stock entropy: game_init's focus draw (:205) and the one of its game_end (:338, turn 0)
+            MtGen mt{S.mt_key + e, N, S.mt_pos[e]};
+            (void)mt_randint(mt, 2u * NG + 1u);
+            (void)mt_randint(mt, 2u * NG + 1u);
+            S.mt_pos[e] = mt.pos;
+        }
     }
     uint64_t rm = __ballot(sel);
     while (rm) {
@@ -989,6 +1040,15 @@ __global__ void __launch_bounds__(WG) evg_reset_kernel(DevState S, const uint8_t
             for (int i = lane; i < 2 * OBS; i += WG) o[i] = (OT)T->reset_obs[i];
         }
     }
+}
+
+// np.random.seed(s) per env (stock-entropy mode): seeds[e], or seed + global env id when seeds == NULL
+__global__ void __launch_bounds__(256) evg_mt_seed_kernel(DevState S, const uint32_t* seeds) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S.N) return;
+    MtGen mt{S.mt_key + e, (size_t)S.N, 0};
+    mt_seed(mt, seeds ? seeds[e] : S.seed_lo + S.env_id_base + (uint32_t)e);
+    S.mt_pos[e] = mt.pos;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1120,6 +1180,18 @@ static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtyp
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool multi = io.turns > 1;
+    if (S.mt_key) {                       // stock-entropy mode: single-turn launches of the sequential-draw instantiation
+        if (multi) return -1;
+        const dim3 grid((S.N + WG / 2 - 1) / (WG / 2)), block(WG);
+        const StepArgs args{S, io};
+        switch (obs_dtype) {
+            case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, WG, false, true>), grid, block, 0, s, args); break;
+            case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, WG, false, true>), grid, block, 0, s, args); break;
+            case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, WG, false, true>), grid, block, 0, s, args); break;
+            default: return -1;
+        }
+        return (int)hipGetLastError();
+    }
     if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
     return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);
 }
@@ -1145,6 +1217,11 @@ int launch_scripted_actions(const DevState& S, int policy, int player, const voi
         case EVG_OBS_I16: hipLaunchKernelGGL(evg_scripted_actions_kernel<int16_t>, grid, block, 0, s, S, policy, player, (const int16_t*)obs, actions); break;
         default: return -1;
     }
+    return (int)hipGetLastError();
+}
+
+int launch_mt_seed(const DevState& S, const uint32_t* seeds_dev, void* stream) {
+    hipLaunchKernelGGL(evg_mt_seed_kernel, dim3((S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, seeds_dev);
     return (int)hipGetLastError();
 }
 

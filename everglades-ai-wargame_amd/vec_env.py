@@ -30,7 +30,10 @@ class EvergladesVecEnv(object):
     obs_len = _lib.OBS_LEN
 
     def __init__(self, num_envs, device=None, seed=0, env_id_base=0, obs_dtype="float32", auto_reset=True, tables=None,
-                 map_file=None, unit_file=None, config_dir=None):
+                 map_file=None, unit_file=None, config_dir=None, rng_mode="philox"):
+        """rng_mode "philox" (default, the fast keyed draws of DESIGN.md section 4) or "mt19937": every env owns numpy's legacy
+        generator seeded like np.random.seed((seed + env_id_base + e) & 0xFFFFFFFF) and consumes it in the reference's
+        order, so a game replays the UNMODIFIED reference process bit for bit (validation mode, sequential draws)."""
         torch = _torch()
         self.L = _lib.load()
         if not torch.cuda.is_available():
@@ -55,6 +58,11 @@ class EvergladesVecEnv(object):
         cfg.num_envs, cfg.device_id = self.num_envs, dev_index
         cfg.seed, cfg.env_id_base = self.seed & 0xFFFFFFFFFFFFFFFF, self.env_id_base
         cfg.obs_dtype, cfg.auto_reset = self._obs_code, int(self.auto_reset)
+        modes = {"philox": _lib.RNG_KEYED_PHILOX, "mt19937": _lib.RNG_STOCK_MT19937}
+        if rng_mode not in modes:
+            raise ValueError("rng_mode must be 'philox' or 'mt19937'")
+        self.rng_mode = rng_mode
+        cfg.rng_mode = modes[rng_mode]
         cfg.tables = tables
         h = C.c_void_p()
         _lib.check(self.L.evg_create(C.byref(cfg), C.byref(h)))
@@ -247,6 +255,27 @@ class EvergladesVecEnv(object):
             raise ValueError("set_state: wrong array shapes")
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         _lib.check(self.L.evg_set_state(self._h, p(g), p(n), p(h), p(e)))
+
+    def seed_stock_entropy(self, seeds=None):
+        """rng_mode="mt19937": np.random.seed(seeds[e]) for every env (None: the create-time rule seed + env_id_base + e)."""
+        a = None
+        if seeds is not None:
+            a = np.ascontiguousarray(np.asarray(seeds, np.uint64) & 0xFFFFFFFF, np.uint32)
+            if a.shape != (self.num_envs,):
+                raise ValueError("seeds must have one entry per env")
+        _lib.check(self.L.evg_seed_stock_entropy(self._h, None if a is None else a.ctypes.data_as(C.c_void_p), self._stream()))
+
+    def get_stock_entropy(self):
+        """uint32 [N, 625]: the 624 key words and the position of every env's MT19937 (np.random.get_state()[1:3])."""
+        a = np.zeros((self.num_envs, 625), np.uint32)
+        _lib.check(self.L.evg_get_stock_entropy(self._h, a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    def set_stock_entropy(self, state):
+        a = np.ascontiguousarray(state, np.uint32)
+        if a.shape != (self.num_envs, 625):
+            raise ValueError("state must be uint32 [N, 625]")
+        _lib.check(self.L.evg_set_stock_entropy(self._h, a.ctypes.data_as(C.c_void_p)))
 
     def episode_stats(self):
         N = self.num_envs

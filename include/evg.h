@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EVG_ABI_VERSION 1
+#define EVG_ABI_VERSION 2
 
 /* Fixed dimensions of the reference environment (everglades_env.py:17-22). */
 #define EVG_NUM_PLAYERS 2
@@ -52,6 +52,16 @@ typedef enum evg_status {
 } evg_status;
 
 typedef enum evg_obs_dtype { EVG_OBS_F32 = 0, EVG_OBS_F64 = 1, EVG_OBS_I16 = 2 } evg_obs_dtype;
+
+/* Source of the combat target draws (server.py:562).
+ *   EVG_RNG_KEYED_PHILOX   the fast path: counter-based draws keyed by (seed, env id, episode, turn, node, player,
+ *                          group, unit) -- DESIGN.md section 4; what every throughput figure is measured with.
+ *   EVG_RNG_STOCK_MT19937  compatibility mode: every env owns the generator the unmodified reference
+ *                          uses -- numpy's legacy MT19937 after np.random.seed(s), randint by masked rejection, consumed
+ *                          in the reference's loop order including its two unobservable focus draws (server.py:205,
+ *                          :338) -- so a game replays the reference process bit for bit.  2.5 KB of extra state per
+ *                          env and sequential draws: for validation, not speed.  Single-turn launches only.        */
+typedef enum evg_rng_mode { EVG_RNG_KEYED_PHILOX = 0, EVG_RNG_STOCK_MT19937 = 1 } evg_rng_mode;
 
 /* game status (server.py:284-288) */
 enum { EVG_IN_PROGRESS = 0, EVG_TIME_EXPIRED = 1, EVG_BASE_CAPTURE = 2, EVG_ANNIHILATION = 3 };
@@ -96,6 +106,8 @@ typedef struct evg_config {
     int32_t  obs_dtype;        /* evg_obs_dtype of obs_out buffers           */
     int32_t  auto_reset;       /* 1: an env that finishes in step() is reset in the same launch and
                                   obs_out holds the first observation of its next episode           */
+    int32_t  rng_mode;         /* evg_rng_mode; in the stock mode env e starts as np.random.seed((uint32)(seed + env_id_base + e)) */
+    int32_t  reserved0;        /* 0 */
     evg_tables tables;
 } evg_config;
 
@@ -227,6 +239,15 @@ int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int p
 int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health, int32_t* env);
 int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, const double* health,
                   const int32_t* env);
+
+/* Stock-entropy mode only (EVG_ERR_INVALID otherwise).
+ * evg_seed_stock_entropy: np.random.seed(seeds[e]) for every env (HOST pointer, N entries; NULL = the create-time rule
+ * (uint32)(seed + env_id_base + e)); enqueued on `stream` after a synchronous upload of the seeds.
+ * evg_get/set_stock_entropy: the generators themselves, HOST uint32 [N][625] = 624 key words + position (the layout of
+ * np.random.get_state()[1:3]); the calls synchronise.  Together with evg_get/set_state this checkpoints a game. */
+int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream);
+int evg_get_stock_entropy(evg_handle* h, uint32_t* out);
+int evg_set_stock_entropy(evg_handle* h, const uint32_t* in);
 
 /* Per-env results of the most recently finished episode, and running totals (device -> host copy,
  * synchronises).  Any pointer may be NULL.

@@ -444,3 +444,103 @@ def test_16_envs_per_wave_variant_matches_oracle(evg, oracle_mod, monkeypatch):
     check_state(env, ora.get_state(), "lanes32")
     assert np.array_equal(env.episode_stats()["totals"], ora.episode_stats()["totals"])
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SURVEY 8 f2 on the device: the stock-entropy mode (rng_mode="mt19937")
+# ---------------------------------------------------------------------------------------------------------------
+def test_stock_entropy_generator_is_numpys(evg):
+    """After seeding, every env's generator is word for word np.random.RandomState(seed) (init_genrand, position 624);
+    explicit per-env seeds and the create-time rule seed + env_id_base + e."""
+    N = 70
+    env = evg.EvergladesVecEnv(N, seed=1234, env_id_base=1000, rng_mode="mt19937")
+    st = env.get_stock_entropy()
+    for e in (0, 1, 33, 69):
+        want = np.random.RandomState(1234 + 1000 + e).get_state()
+        assert np.array_equal(st[e, :624], want[1]) and st[e, 624] == want[2] == 624
+    seeds = np.arange(N, dtype=np.uint64) * 7919 + 2 ** 32 - 5
+    env.seed_stock_entropy(seeds)
+    st = env.get_stock_entropy()
+    for e in (0, 2, 69):
+        assert np.array_equal(st[e, :624], np.random.RandomState(int(seeds[e]) & 0xFFFFFFFF).get_state()[1])
+    env.close()
+    keyed = evg.EvergladesVecEnv(4, seed=1)
+    with pytest.raises(evg.EvgError):
+        keyed.seed_stock_entropy()
+    keyed.close()
+
+
+def test_stock_entropy_mode_replays_the_unmodified_reference(evg):
+    """tests/golden/stock_mt.npz: 8 games of the reference with NO entropy injection (np.random.seed(s), its own
+    np.random.randint incl. the unobservable focus draws).  The device in stock mode, given the same seeds and orders,
+    reproduces every observation, score, status and the float64 health bit for bit -- all 8 games side by side."""
+    d = load_golden("stock_mt.npz")
+    G = len(d["length"])
+    env = evg.EvergladesVecEnv(G, seed=0, auto_reset=False, obs_dtype="float64", rng_mode="mt19937")
+    env.seed_stock_entropy(d["seed"])
+    obs = _np(env.reset())
+    for g in range(G):
+        assert np.array_equal(obs[g], d["obs"][g, 0].astype(np.float64))
+    T = int(d["length"].max())
+    for t in range(T):
+        live = [g for g in range(G) if t < int(d["length"][g])]
+        a = np.zeros((G, 2, 7, 2), np.int32)
+        for g in live:
+            a[g] = d["actions"][g, t]
+        obs, rew, done, info = env.step(a)
+        obs, sc, stt = _np(obs), _np(info["scores"]), _np(info["status"])
+        s = env.get_state()
+        for g in live:
+            assert np.array_equal(obs[g], d["obs"][g, t + 1].astype(np.float64)), ("obs", g, t)
+            assert np.array_equal(sc[g], d["scores"][g, t]) and stt[g] == d["status"][g, t], ("scores", g, t)
+            assert np.array_equal(s["health"][g], d["health"][g, t + 1]), ("health bits", g, t)
+    env.close()
+
+
+@pytest.mark.parametrize("policy", ["random", "brawl"])
+def test_stock_entropy_rollout_vs_oracle(evg, oracle_mod, policy):
+    """Stock mode at a ragged size (partial last wavefront) over several auto-reset episodes: the per-env MT19937
+    streams (regenerated every 624 outputs, two focus draws per reset, one every tenth turn) stay in lock-step with the
+    oracle's literal restatement of the reference's loops."""
+    from gen_policies import policy_actions
+    N, seed, base = 300, 77, 5000
+    env = evg.EvergladesVecEnv(N, seed=seed, env_id_base=base, auto_reset=True, rng_mode="mt19937")
+    ora = oracle_mod.Oracle(N, seed=seed, env_id_base=base, auto_reset=True)
+    ora.use_stock_mt((seed + base + np.arange(N)) & 0xFFFFFFFF)
+    obs = _np(env.reset()).astype(np.float64)
+    assert np.array_equal(obs, ora.reset())
+    rng = np.random.default_rng(11)
+    for t in range(330):
+        a = _np(env.random_actions()).copy() if policy == "random" else policy_actions(policy, obs, t, rng)
+        o, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(a)
+        obs = _np(o).astype(np.float64)
+        assert np.array_equal(obs, o_obs), (policy, "obs", t)
+        assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(done), o_done)
+        if t % 55 == 54:
+            check_state(env, ora.get_state(), (policy, t))
+    assert env.episode_stats()["totals"][0] >= N
+    env.close()
+
+
+def test_stock_entropy_checkpoint_roundtrip(evg):
+    """evg_get/set_state + evg_get/set_stock_entropy checkpoint a stock-mode game: restoring both and replaying the same
+    orders gives the same trajectory; the native rollout driver works in this mode too (single-turn launches)."""
+    N = 96
+    env = evg.EvergladesVecEnv(N, seed=3, auto_reset=True, rng_mode="mt19937")
+    env.reset()
+    env.rollout_random(40, turns_per_launch=150)           # clamps to one turn per launch in this mode
+    s, m = env.get_state(), env.get_stock_entropy()
+    assert (m[:, 624] <= 624).all() and len(set(m[:, 624].tolist())) > 1
+    acts, outs = [], []
+    for t in range(25):
+        a = env.random_actions().clone()
+        acts.append(a)
+        outs.append(_np(env.step(a)[0]).copy())
+    end = env.get_state()
+    env.set_state(**s)
+    env.set_stock_entropy(m)
+    for t in range(25):
+        assert np.array_equal(_np(env.step(acts[t])[0]), outs[t]), t
+    check_state(env, end, "restored replay")
+    env.close()
