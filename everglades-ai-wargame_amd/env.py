@@ -57,7 +57,18 @@ def canonical_actions(action):
 class EvergladesEnv(object):
     metadata = {"render.modes": []}
 
-    def __init__(self, seed=None, device=None, env_id=0):
+    def __init__(self, seed=None, device=None, env_id=0, entropy="philox"):
+        """entropy: where the combat target draws (server.py:562) come from.
+          "philox"   keyed counter-based draws (DESIGN.md section 4), `seed` is the key (random when omitted);
+          "mt19937"  the env owns numpy's legacy generator, started like np.random.seed(seed);
+          "numpy"    the process-wide np.random generator itself, shared with everything else in the process exactly
+                     as in the reference (its server and e.g. the random_actions agents interleave draws on that one
+                     stream): np.random.seed(s) followed by an unchanged harness loop plays the same game, bit for
+                     bit, as the reference process does.  The generator travels to the device and back around every
+                     reset/step (two small copies; this single-game class is not the throughput path)."""
+        if entropy not in ("philox", "mt19937", "numpy"):
+            raise ValueError("entropy must be 'philox', 'mt19937' or 'numpy'")
+        self._entropy = entropy
         self.num_turns = 150
         self.num_units = 100
         self.num_groups = 12
@@ -79,8 +90,29 @@ class EvergladesEnv(object):
             if self._vec is not None:
                 self._vec.close()
             tables = default_tables() if (map_file is None and unit_file is None) else tables_from_json(map_file, unit_file, config_dir)
-            self._vec = EvergladesVecEnv(1, device=self._device, seed=self._seed, env_id_base=self._env_id, obs_dtype="float64", auto_reset=False, tables=tables)
+            self._vec = EvergladesVecEnv(1, device=self._device, seed=self._seed, env_id_base=self._env_id, obs_dtype="float64", auto_reset=False, tables=tables,
+                                         rng_mode="philox" if self._entropy == "philox" else "mt19937")
+            if self._entropy == "mt19937":
+                self._vec.seed_stock_entropy([self._seed & 0xFFFFFFFF])
             self._cfg_key = key
+
+    def _lend_numpy(self):
+        """entropy="numpy": hand the process-wide generator to the device ..."""
+        if self._entropy != "numpy":
+            return None
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            raise _lib.EvgError("np.random is not the legacy MT19937 generator")
+        buf = np.empty((1, 625), np.uint32)
+        buf[0, :624], buf[0, 624] = st[1], st[2]
+        self._vec.set_stock_entropy(buf)
+        return st
+
+    def _return_numpy(self, st):
+        """... and take it back, advanced by what the game consumed."""
+        if st is not None:
+            m = self._vec.get_stock_entropy()
+            np.random.set_state((st[0], m[0, :624].copy(), int(m[0, 624]), st[3], st[4]))
 
     def _obs_dict(self, obs):
         o = obs[0].cpu().numpy()
@@ -97,7 +129,10 @@ class EvergladesEnv(object):
         self.sorted_pks = sorted(self.pks)
         assert self.sorted_pks == [0, 1], "Given player number not included in map configuration file starting locations"
         self._ensure(config_dir, map_file, unit_file)
-        return self._obs_dict(self._vec.reset())
+        st = self._lend_numpy()
+        obs = self._obs_dict(self._vec.reset())
+        self._return_numpy(st)
+        return obs
 
     def step(self, actions):
         a = np.zeros((1, 2, 7, 2), np.int32)
@@ -106,8 +141,10 @@ class EvergladesEnv(object):
                 print("Player {} not found in input action dictionary".format(p))   # server.py:219-221
                 continue
             a[0, i] = canonical_actions(actions[p])
+        st = self._lend_numpy()
         obs, _, done, info = self._vec.step(a)
         observations = self._obs_dict(obs)
+        self._return_numpy(st)
         scores = info["scores"][0].cpu().numpy()
         status = int(info["status"][0].item())
         reward = {p: 0 for p in self.players}

@@ -457,17 +457,19 @@ class _AgentNpProxy(object):
 _agent_module_counter = [0]
 
 
-def load_agent(proxy, filename, classname, player):
-    """A fresh copy of the module per agent object, so the module-global ATTACK_LIST of swarm_agent.py is per agent."""
+def load_agent(proxy, filename, classname, player, stock=False):
+    """A fresh copy of the module per agent object, so the module-global ATTACK_LIST of swarm_agent.py is per agent.
+    stock=True leaves the module's own numpy / random in place (no entropy injection)."""
     import importlib.util
     _agent_module_counter[0] += 1
     spec = importlib.util.spec_from_file_location("evg_ref_agent_%d" % _agent_module_counter[0],
                                                   os.path.join(REF, "agents", "State_Machine", filename))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    mod.np = _AgentNpProxy(proxy)
-    if hasattr(mod, "random"):
-        mod.random = _StdRandomProxy(proxy)
+    if not stock:
+        mod.np = _AgentNpProxy(proxy)
+        if hasattr(mod, "random"):
+            mod.random = _StdRandomProxy(proxy)
     cls = getattr(mod, classname)
     import inspect
     nargs = len(inspect.signature(cls.__init__).parameters) - 1
@@ -565,6 +567,37 @@ def gen_stock_mt_fixture(R):
     print("stock_mt:", d["length"].tolist(), [int(s[l - 1]) for s, l in zip(d["status"], d["length"])], flush=True)
 
 
+def gen_config1_fixture(R):
+    """BASELINE config 1 as the reference runs it, nothing injected anywhere: np.random.seed(0), the reference's own
+    random_actions agents on both seats (they draw from the SAME global numpy generator as the server, so agent and
+    server draws interleave in one stream), DemoMap, two consecutive episodes in one process (evaluate.py's loop shape:
+    agents built once, env.reset() per episode)."""
+    R.server.np = np
+    np.random.seed(0)
+    agents = [load_agent(None, "random_actions.py", "random_actions", p, stock=True) for p in (0, 1)]
+    EP = 2
+    d = dict(obs=np.zeros((EP, 151, 2, 105), np.int16), actions=np.zeros((EP, 150, 2, 7, 2), np.int8), length=np.zeros(EP, np.int32),
+             reward=np.zeros((EP, 150, 2), np.float64), done=np.zeros((EP, 150), np.uint8), seed=np.array([0], np.uint64))
+    for ep in range(EP):
+        obs = R.env.reset(players={0: None, 1: None}, **R.cfg)
+        d["obs"][ep, 0] = np.stack([obs[0], obs[1]])
+        done, t = 0, 0
+        while not done:
+            acts = {p: agents[p].get_action(obs[p]) for p in (0, 1)}          # demo/random_demo.py:100-103
+            obs, reward, done, info = R.env.step(acts)
+            d["actions"][ep, t] = np.stack([canon_actions(acts[0]), canon_actions(acts[1])])
+            d["reward"][ep, t] = [reward[0], reward[1]]
+            d["done"][ep, t] = done
+            t += 1
+            d["obs"][ep, t] = np.stack([obs[0], obs[1]])
+        d["length"][ep] = t
+    st = np.random.get_state()
+    d["final_key"], d["final_pos"] = np.asarray(st[1], np.uint32), np.array([st[2]], np.int32)
+    R.server.np = R.proxy
+    np.savez_compressed(os.path.join(OUT, "config1_stock.npz"), **d)
+    print("config1_stock:", d["length"].tolist(), d["reward"][np.arange(EP), d["length"] - 1].tolist(), int(st[2]), flush=True)
+
+
 def gen_smart_state_fixture():
     """the per-swarm 'smart state' preprocessing of agents/Smart_State/DQNAgent.py:200-300 and the move
     table of Move_Translation.py, evaluated by the reference's own functions on observations of committed trajectories."""
@@ -634,6 +667,9 @@ def main():
     if os.environ.get("EVG_GOLDEN_ONLY") == "stock":
         gen_stock_mt_fixture(R)
         return
+    if os.environ.get("EVG_GOLDEN_ONLY") == "config1":
+        gen_config1_fixture(R)
+        return
     if os.environ.get("EVG_GOLDEN_ONLY") == "smart":
         gen_smart_state_fixture()
         return
@@ -672,6 +708,7 @@ def main():
 
     gen_smart_state_fixture()
     gen_stock_mt_fixture(R)
+    gen_config1_fixture(R)
 
     # 4. bulk random-vs-random: outcomes + per-turn checksums only
     B = 120

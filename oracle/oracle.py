@@ -83,6 +83,7 @@ def lib():
         L.evo_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.evo_observe.argtypes = [C.c_void_p, C.c_void_p]
         L.evo_use_stock_mt.argtypes = [C.c_void_p, C.c_void_p]
+        L.evo_mt_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.evo_mt_randint_stream.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.evo_smart_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.evo_get_move.restype = C.c_int
@@ -159,6 +160,15 @@ class Oracle(object):
         sd = np.ascontiguousarray(seeds, np.uint32)
         assert sd.shape == (self.n,)
         self.L.evo_use_stock_mt(self.h, _p(sd))
+
+    def get_stock_entropy(self):
+        a = np.zeros((self.n, 625), np.uint32)
+        assert self.L.evo_mt_state(self.h, 0, _p(a)) == 0
+        return a
+
+    def set_stock_entropy(self, state):
+        a = np.ascontiguousarray(state, np.uint32)
+        assert a.shape == (self.n, 625) and self.L.evo_mt_state(self.h, 1, _p(a)) == 0
 
     def scripted_actions(self, policy, player, obs, out=None):
         """policy: 1 Cycle_BRush_Turn25, 2 Cycle_BRush_Turn50, 3 SwarmAgent; writes rows [:, player] of `out`."""

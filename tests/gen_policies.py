@@ -69,3 +69,16 @@ def policy_actions(policy, obs, t, rng):
     if policy == "wild":
         return wild_actions(obs.shape[0], rng)
     raise KeyError(policy)
+
+
+class NumpyGlobalRandomAgent(object):
+    """What agents/State_Machine/random_actions.py:38-46 does, as a test stand-in (the reference is not importable on the
+    GPU box): two draws without replacement from numpy's GLOBAL generator per call -- the same stream the reference's
+    server draws combat targets from, so agent and server draws interleave.  Pinned by the action streams recorded in
+    tests/golden/config1_stock.npz from the reference's own agent class."""
+
+    def get_action(self, obs):
+        a = np.zeros((7, 2))
+        a[:, 0] = np.random.choice(12, 7, replace=False)
+        a[:, 1] = np.random.choice(list(range(1, 12)), 7, replace=False)
+        return a

@@ -544,3 +544,34 @@ def test_stock_entropy_checkpoint_roundtrip(evg):
         assert np.array_equal(_np(env.step(acts[t])[0]), outs[t]), t
     check_state(env, end, "restored replay")
     env.close()
+
+
+def test_dropin_shares_numpys_global_generator_like_the_reference(evg):
+    """BASELINE config 1 as the reference process runs it (tests/golden/config1_stock.npz: np.random.seed(0), the
+    reference's own random_actions agents, nothing injected).  With entropy="numpy" the drop-in env borrows the
+    process-wide generator around every reset/step, so an unchanged harness loop -- np.random.seed(0), agents that draw
+    from np.random, env.reset()/env.step() -- plays the very same two episodes on the GPU: agent orders, observations,
+    rewards, done flags and the final state of np.random are all equal to the reference's."""
+    from gen_policies import NumpyGlobalRandomAgent
+    d = load_golden("config1_stock.npz")
+    saved = np.random.get_state()
+    try:
+        np.random.seed(int(d["seed"][0]))
+        env = evg.EvergladesEnv(entropy="numpy")
+        players = {0: NumpyGlobalRandomAgent(), 1: NumpyGlobalRandomAgent()}
+        for ep in range(len(d["length"])):
+            obs = env.reset(players=players, config_dir=None, map_file=None, unit_file=None, output_dir=None, pnames=None, debug=False)
+            assert all(np.array_equal(obs[p], d["obs"][ep, 0, p].astype(np.float64)) for p in (0, 1))
+            done, t = 0, 0
+            while not done:
+                actions = {p: players[p].get_action(obs[p]) for p in (0, 1)}
+                assert all(np.array_equal(actions[p].astype(int), d["actions"][ep, t, p]) for p in (0, 1)), ("agent stream", ep, t)
+                obs, reward, done, info = env.step(actions)
+                assert all(np.array_equal(obs[p], d["obs"][ep, t + 1, p].astype(np.float64)) for p in (0, 1)), ("obs", ep, t)
+                assert [reward[0], reward[1]] == d["reward"][ep, t].tolist() and int(done) == int(d["done"][ep, t]), ("reward", ep, t)
+                t += 1
+            assert t == int(d["length"][ep])
+        fin = np.random.get_state()
+        assert np.array_equal(fin[1], d["final_key"]) and fin[2] == int(d["final_pos"][0])
+    finally:
+        np.random.set_state(saved)

@@ -165,3 +165,43 @@ def test_unmodified_reference_with_stock_entropy(oracle_mod):
             s = o.get_state()
             assert np.array_equal(s["health"][0], d["health"][g, t + 1]), ("health bits", g, t)
             assert np.array_equal(s["rank"][0], d["rank"][g, t + 1])
+
+
+def test_config1_shared_numpy_stream(oracle_mod):
+    """BASELINE config 1 exactly as the reference runs it (tests/golden/config1_stock.npz: np.random.seed(0), the
+    reference's own random_actions agents, nothing injected): agents and server draw from ONE global generator.  The
+    oracle borrows that generator around every reset/step (evo_mt_state) and a stand-in agent draws from it in between:
+    actions, observations, rewards and the final generator state all match the reference process over two episodes."""
+    from gen_policies import NumpyGlobalRandomAgent
+    d = load_golden("config1_stock.npz")
+    saved = np.random.get_state()
+    try:
+        np.random.seed(int(d["seed"][0]))
+        o = oracle_mod.Oracle(1, seed=0)
+        o.use_stock_mt([0])
+
+        def lend():
+            st = np.random.get_state()
+            o.set_stock_entropy(np.concatenate([st[1], [st[2]]]).astype(np.uint32)[None])
+            return st
+
+        def take_back(st):
+            m = o.get_stock_entropy()[0]
+            np.random.set_state((st[0], m[:624].copy(), int(m[624]), st[3], st[4]))
+
+        agents = [NumpyGlobalRandomAgent(), NumpyGlobalRandomAgent()]
+        for ep in range(len(d["length"])):
+            st = lend(); obs = o.reset(); take_back(st)
+            assert np.array_equal(obs[0], d["obs"][ep, 0].astype(np.float64))
+            for t in range(int(d["length"][ep])):
+                a = np.stack([agents[p].get_action(obs[0, p]) for p in (0, 1)]).astype(np.int32)
+                assert np.array_equal(a, d["actions"][ep, t]), ("agent stream", ep, t)
+                st = lend(); obs, reward, done, info = o.step(a[None]); take_back(st)
+                assert np.array_equal(obs[0], d["obs"][ep, t + 1].astype(np.float64)), ("obs", ep, t)
+                assert int(done[0]) == int(d["done"][ep, t])
+                if not done[0]:
+                    assert np.allclose(reward[0], d["reward"][ep, t], rtol=0, atol=1e-12)
+        fin = np.random.get_state()
+        assert np.array_equal(fin[1], d["final_key"]) and fin[2] == int(d["final_pos"][0])
+    finally:
+        np.random.set_state(saved)
