@@ -2,6 +2,7 @@
 // Owns the persistent device state of one handle, validates and flattens the constant tables,
 // and enqueues the kernels of evg_kernels.hip on the caller's stream.  No CPU execution path.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -158,6 +159,22 @@ static int build_dev_tables(const evg_config* cfg, DevTables* D) {
         D->armor_byte |= (uint32_t)t.unit_health[u] << (8 * u);
         D->unit_speed[u] = t.unit_speed[u]; D->unit_control[u] = t.unit_control[u]; D->unit_cost[u] = t.unit_cost[u];
     }
+    // Combat divides (10 * D) by armor (+ node defense); D <= 255 and the denominators are the few values below, so the
+    // quotient can be taken as q0 = a * rcp, q = fma(fma(-den, q0, a), rcp, q0) -- IF that equals the IEEE quotient, which is
+    // checked here for every case that can occur with these tables (the kernel keeps a true division for tables that fail)
+    D->fast_div = 1;
+    for (int u = 0; u < t.num_unit_types; ++u)
+        for (int n = 0; n <= NN; ++n) {
+            const double den = (double)t.unit_health[u] + (n ? t.node_defense[n] : 0.0);
+            const double rcp = 1.0 / den;
+            D->den_tab[u][n] = den;
+            D->rcp_tab[u][n] = rcp;
+            for (int dsum = 0; dsum <= 255; ++dsum) {
+                const double a = 10.0 * (double)dsum, q0 = a * rcp;
+                const double q = fma(fma(-den, q0, a), rcp, q0);
+                if (!(q == a / den)) D->fast_div = 0;
+            }
+        }
     int start[2] = {-1, -1};
     bool seen[12] = {false};
     for (int n = 1; n <= NN; ++n) {

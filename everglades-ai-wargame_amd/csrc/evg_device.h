@@ -52,6 +52,10 @@ struct DevTables {
     uint64_t p1inv_nib;          // nibble n = slot of p1's board view that shows node n (inverse of p1_node_map)
     uint32_t damage_nib;         // nibble t = damage of unit type t
     uint32_t armor_byte;         // byte t   = health ("armor") of unit type t
+    double   den_tab[4][12];     // combat denominator of a target of unit type t: [t][0] = armor, [t][n] = armor + defense of node n (:592-601)
+    double   rcp_tab[4][12];     // its correctly rounded reciprocal (host division)
+    int32_t  fast_div;           // 1: (10 * D) / den == fma(fma(-den, q0, a), rcp, q0) with q0 = a * rcp for EVERY damage sum D in 0..255 and
+                                 // every table entry (checked exhaustively at evg_create) -- the kernel then divides with 3 flops
     int32_t  unit_speed[4], unit_control[4], unit_cost[4];
     int32_t  group_type[2][12];
     int32_t  max_turns;

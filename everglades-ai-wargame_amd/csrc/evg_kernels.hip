@@ -61,7 +61,7 @@ struct __align__(16) StepLds {
         int16_t  O[LPW * OBS];           // observations of the wave's envs, already in output order [env][player][105]
     } u;
     uint64_t adj[12];
-    double   defense[12];
+    double   den[48], rcp[48];           // DevTables::den_tab / rcp_tab (indexed per lane)
 };
 
 // 12-input sorting network (tools/gen_sort12.py: 42 compare-exchanges, verified with the 0-1 principle)
@@ -314,10 +314,13 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const DevTables* T = S.T;
 
     STAMP(0);
-    // ---- constant tables: adjacency/defense to LDS (indexed per lane), the rest into scalar registers
+    // ---- constant tables: adjacency and combat denominators to LDS (indexed per lane), the rest into scalar registers
     if (lane < 12) {
         L.adj[lane] = T->adj_row[lane];
-        L.defense[lane] = T->defense[lane];
+    }
+    if (lane < 48) {
+        L.den[lane] = (&T->den_tab[0][0])[lane];
+        L.rcp[lane] = (&T->rcp_tab[0][0])[lane];
     }
 
     // ---- load state (env fastest; the two player rows of a group index interleave across lanes)
@@ -512,7 +515,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int excl_i = excl & 0xFFFF, excl_d = excl >> 16, tot_i = tot & 0xFFFF, tot_d = tot >> 16, mid_i = mid & 0xFFFF, mid_d = mid >> 16;
         // the pool holds every fight of the wave in the common case; otherwise two passes of 16 envs each
         const int npass = tot_d <= DP_CAP ? 1 : 2;
-        const uint32_t dmg_nib = T->damage_nib, armor_byte = T->armor_byte;
+        const uint32_t dmg_nib = T->damage_nib;
+        const bool fast_div = T->fast_div != 0;
         for (int ps = 0; ps < npass; ++ps) {
             const bool inpass = npass == 1 || (lane / (LPW / 2)) == ps;     // helper lanes own no items
             const int ref_i = (npass == 2 && ps == 1) ? mid_i : 0, ref_d = (npass == 2 && ps == 1) ? mid_d : 0;
@@ -665,17 +669,30 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                     const uint64_t tn_s = side ? T->type_nib[1] : T->type_nib[0];
                     const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
-                    const double armor = (double)((armor_byte >> (8 * type)) & 0xFFu);
                     const int ctrl_by = (int)((L.NW[node][SL >> 1] >> 10) & 3u) - 1;
-                    const double denom = armor + (ctrl_by == side ? L.defense[node] : 0.0);          // :592-597 (fort bonus dead)
+                    const int di = (int)type * 12 + (ctrl_by == side ? node : 0);                    // :592-597 (fort bonus dead)
+                    const double denom = L.den[di], rcp = L.rcp[di];
                     uint32_t newmask = mask;
+                    if (fast_div) {
 #pragma unroll
-                    for (int sl = 0; sl < 12; ++sl) {            // unconditional: an untouched unit loses exactly 0.0
-                        const double loss = (10.0 * (double)dmv[sl]) / denom;                         // :601
-                        double hv = h[sl] - loss;                                                     // :609
-                        const bool dead = hv <= 0.0;                                                  // :615-618
-                        h[sl] = dead ? 0.0 : hv;
-                        newmask &= dead ? ~(1u << sl) : ~0u;
+                        for (int sl = 0; sl < 12; ++sl) {        // unconditional: an untouched unit loses exactly 0.0
+                            const double a = (double)(10u * dmv[sl]);                                 // exact, like 10. * tgt_dmg
+                            const double q0 = a * rcp;
+                            const double loss = __builtin_fma(__builtin_fma(-denom, q0, a), rcp, q0); // == a / denom (DevTables::fast_div)
+                            double hv = h[sl] - loss;                                                 // :609
+                            const bool dead = hv <= 0.0;                                              // :615-618
+                            h[sl] = dead ? 0.0 : hv;
+                            newmask &= dead ? ~(1u << sl) : ~0u;
+                        }
+                    } else {
+#pragma unroll
+                        for (int sl = 0; sl < 12; ++sl) {
+                            const double loss = (10.0 * (double)dmv[sl]) / denom;                     // :601
+                            double hv = h[sl] - loss;
+                            const bool dead = hv <= 0.0;
+                            h[sl] = dead ? 0.0 : hv;
+                            newmask &= dead ? ~(1u << sl) : ~0u;
+                        }
                     }
                     double2* w2 = reinterpret_cast<double2*>(row);
 #pragma unroll
