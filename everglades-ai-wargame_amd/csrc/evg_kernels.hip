@@ -359,6 +359,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int lane_ = threadIdx.x;
     if (MULTI) { asm volatile("" : "+s"(A)); asm volatile("" : "+v"(lane_)); T = S.T; }
     const int lane = lane_;
+    if (MULTI) STAMP(0);                                // diagnostic build: the stamps of a launch are those of its last turn
     const bool envlane = LPW == WG || lane < LPW;
     const int E = envlane ? lane >> 1 : 0, P = lane & 1;
     const int col = envlane ? lane : 0;                 // LDS column (helpers never write; their reads are discarded)
