@@ -414,8 +414,16 @@ int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs,
 int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void* stream) {
     if (!h || (!fog_out && !knowledge_out)) return fail(EVG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    const int rc = launch_fog(h->S, fog_out, knowledge_out, stream);
+    const int rc = launch_fog(h->S, fog_out, knowledge_out, nullptr, stream);
     if (rc) return fail(EVG_ERR_HIP, "fog launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream) {
+    if (!h || !sight_out) return fail(EVG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int rc = launch_fog(h->S, nullptr, nullptr, sight_out, stream);
+    if (rc) return fail(EVG_ERR_HIP, "sightings launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
 

@@ -112,7 +112,7 @@ int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtyp
 int launch_random_actions(const DevState& S, int32_t* actions, void* stream);
 int launch_scripted_actions(const DevState& S, int policy, int player, const void* obs, int32_t* actions, int obs_dtype, void* stream);
 int launch_scripted_reset(const DevState& S, void* stream);
-int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, void* stream);
+int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, int8_t* sight, void* stream);
 int launch_mt_seed(const DevState& S, const uint32_t* seeds_dev, void* stream);
 int launch_smart_state(const DevState& S, int player, const void* obs, float* out, int obs_dtype, void* stream);
 

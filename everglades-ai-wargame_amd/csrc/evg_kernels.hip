@@ -1113,9 +1113,10 @@ __global__ void evg_scripted_reset_kernel(DevState S) {
 // ---------------------------------------------------------------------------------------------
 // fog-of-war planes: the `valid_nodes` mask of board_state (server.py:402-425) and the per-node knowledge
 // levels of build_knowledge_output (server.py:779-832) -- both computed by the reference and never applied to the
-// observation; exposed here as optional planes.  One thread per (env, player); real node order.
+// observation; exposed here as optional planes, plus the opposing-group sightings of :845-907.  One thread per (env, player);
+// real node order.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* fog, uint8_t* know) {
+__global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* fog, uint8_t* know, int8_t* sight) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 2 * S.N) return;
     const int e = idx >> 1, p = idx & 1;
@@ -1147,6 +1148,21 @@ __global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* fog, 
     for (int n = 1; n <= NN; ++n) {
         if (fog) fog[(size_t)idx * NN + n - 1] = (uint8_t)((valid >> n) & 1u);
         if (know) know[(size_t)idx * NN + n - 1] = (uint8_t)(((full >> n) & 1u) ? 2u : (((partial >> n) & 1u) ? 1u : 0u));
+    }
+    if (sight) {
+        // opposing-group sightings `opp_k` (server.py:845-907): a listed opposing group is reported at its node when that node's
+        // knowledge is 1 or 2 and it is either not moving (key -1) or headed for a node of knowledge > 0 (key = that node's
+        // index in the node list, ID - 1, as the reference writes it): {seen, node, key, unit count} per opposing group
+        const uint32_t known = full | partial;
+        char4* out = reinterpret_cast<char4*>(sight) + (size_t)idx * NG;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t w = S.grp[(size_t)((1 - p) * 12 + k) * N + e];
+            const bool alive = (w & G_MASK_M) != 0, moving = ((w & G_MODE_M) >> G_MODE_S) == MODE_MOVING;
+            const uint32_t loc = w & G_LOC_M, dest = (w & G_DEST_M) >> G_DEST_S;
+            const bool seen = alive && ((known >> loc) & 1u) && (!moving || ((known >> dest) & 1u));
+            out[k] = seen ? make_char4(1, (signed char)loc, (signed char)(moving ? (int)dest - 1 : -1), (signed char)__popc(w & G_MASK_M)) : make_char4(0, 0, 0, 0);
+        }
     }
 }
 
@@ -1261,8 +1277,8 @@ int launch_smart_state(const DevState& S, int player, const void* obs, float* ou
     return (int)hipGetLastError();
 }
 
-int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, void* stream) {
-    hipLaunchKernelGGL(evg_fog_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, fog, know);
+int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, int8_t* sight, void* stream) {
+    hipLaunchKernelGGL(evg_fog_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, fog, know, sight);
     return (int)hipGetLastError();
 }
 

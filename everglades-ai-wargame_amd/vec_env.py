@@ -168,6 +168,17 @@ class EvergladesVecEnv(object):
         _lib.check(self.L.evg_fog_of_war(self._h, None, self._ptr(out), self._stream()))
         return out
 
+    def sightings(self, out=None):
+        """int8 [N, 2, 12, 4]: what player p knows of opposing group g -- (seen, node id, destination key, units alive) --
+        the `opp_k` of build_knowledge_output (server.py:845-907); key -1 = staying, else the destination's index (ID - 1)."""
+        torch = _torch()
+        if out is None:
+            if getattr(self, "_sight", None) is None:
+                self._sight = torch.zeros((self.num_envs, 2, _lib.NUM_GROUPS, 4), dtype=torch.int8, device=self.device)
+            out = self._sight
+        _lib.check(self.L.evg_sightings(self._h, self._ptr(out), self._stream()))
+        return out
+
     def smart_state(self, player, obs=None, out=None):
         """float32 [N, 12, 59]: the per-swarm input of the reference's Smart_State agents (DQNAgent.create_swarm_obs) for
         seat `player`, computed on device from `obs` (default: the env's observation buffer)."""

@@ -161,6 +161,13 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream);
  * Real node order, not mirrored for player 1, exactly as the reference computes them. */
 int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void* stream);
 
+/* The opposing-group sightings `opp_k` of build_knowledge_output (server.py:845-907), also computed and dropped by the
+ * reference.  sight_out: device int8 [N][2][12][4]; [e][p][g] = what player p knows of opposing group g:
+ *   {seen, node ID, destination key, units alive}.  seen = 1 iff the group is listed at a node whose knowledge level is 1 or 2
+ *   and it is either not moving (key -1) or moving to a node of knowledge > 0 (key = that node's index in the node list,
+ *   i.e. ID - 1 -- the reference keys stationary groups by -1 and moving ones by the list index, :866-881); else 0,0,0,0. */
+int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream);
+
 /* Consumer-side preprocessing of the reference's strongest agent family (agents/Smart_State/DQNAgent.py:200-300,
  * create_swarm_obs): from `player`'s rows of obs (device [N][2][105] of cfg.obs_dtype) to features_out, device float
  * [N][12][59]: per swarm {turn/150, 11 x control/100, 11 x enemy units/100, 11 x idle allied groups/12, one-hot node,

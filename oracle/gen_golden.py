@@ -142,10 +142,14 @@ class FogTap(object):
 
 
 def knowledge_levels(game):
-    """The per-node knowledge levels (0 none, 1 partial, 2 full) that build_knowledge_output (server.py:769-835) computes
-    into a local list and only formats into a dropped string.  The function mutates nothing, so it is called once per
-    player (team_starts temporarily narrowed to that player) with a profiler hook reading the local at return."""
+    """The per-node knowledge levels (0 none, 1 partial, 2 full) and the opposing-group sightings `opp_k` that
+    build_knowledge_output (server.py:769-907) computes into locals and only formats into dropped strings.  The function
+    mutates nothing, so it is called once per player (team_starts temporarily narrowed to that player) with a profiler
+    hook reading the locals at return.  Returns (levels uint8 [2][11], sightings int8 [2][12][4]): the sightings of
+    observer pid are opp_k flattened in its own iteration order -- one row (node id, destination key, unit type id,
+    unit count) per reported opposing group, rows of -2 after the last."""
     out = np.zeros((2, NN), np.uint8)
+    sight = np.full((2, NG, 4), -2, np.int8)
     saved = game.team_starts
     for pid in (0, 1):
         box = {}
@@ -153,6 +157,8 @@ def knowledge_levels(game):
         def hook(frame, event, arg, _b=box):
             if event == "return" and frame.f_code.co_name == "build_knowledge_output":
                 _b["k"] = list(frame.f_locals["knowledge"])
+                _b["opp_k"] = {nid: {dst: dict(unitTypes=list(v["unitTypes"]), unitCount=list(v["unitCount"])) for dst, v in dd.items()}
+                               for nid, dd in frame.f_locals["opp_k"].items()}
 
         game.team_starts = {pid: saved[pid]}
         sys.setprofile(hook)
@@ -162,7 +168,12 @@ def knowledge_levels(game):
             sys.setprofile(None)
             game.team_starts = saved
         out[pid] = box["k"]
-    return out
+        rows = [(nid, dst, game.unit_names[ut.lower()], uc) for nid, dd in box["opp_k"].items() for dst, v in dd.items()
+                for ut, uc in zip(v["unitTypes"], v["unitCount"])]
+        assert len(rows) <= NG
+        for i, r in enumerate(rows):
+            sight[pid, i] = r
+    return out, sight
 
 
 class Tracker(object):
@@ -343,7 +354,9 @@ class Runner(object):
                for p in (0, 1)]
         pols = POLICIES[policy] if policy in POLICIES else (pol_zero, pol_zero)
         rec = dict(obs=[np.stack([obs[0], obs[1]])], actions=[], raw0=[], raw1=[], reward=[], done=[], scores=[],
-                   status=[], groups=[], nodes=[], health=[], rank=[], fog=[tap.snapshot()], know=[knowledge_levels(game)])
+                   status=[], groups=[], nodes=[], health=[], rank=[], fog=[tap.snapshot()], know=[], sight=[])
+        kl, sg = knowledge_levels(game)
+        rec["know"].append(kl), rec["sight"].append(sg)
         g, n, h, r = tr.snapshot()
         rec["groups"].append(g), rec["nodes"].append(n), rec["health"].append(h), rec["rank"].append(r)
         done, t = 0, 0
@@ -366,7 +379,8 @@ class Runner(object):
                 obs, reward, done, info = self.env.step({0: a0, 1: a1})
             game.game_turn = orig
             rec["fog"].append(tap.snapshot())
-            rec["know"].append(knowledge_levels(game))
+            kl, sg = knowledge_levels(game)
+            rec["know"].append(kl), rec["sight"].append(sg)
             tr.after_turn()
             t += 1
             rec["actions"].append(np.stack([canon_actions(a0), canon_actions(a1)]))
@@ -378,7 +392,7 @@ class Runner(object):
             g, n, h, r = tr.snapshot()
             rec["groups"].append(g), rec["nodes"].append(n), rec["health"].append(h), rec["rank"].append(r)
         out = dict(length=t)
-        for k in ("obs", "actions", "reward", "done", "scores", "status", "groups", "nodes", "health", "rank", "fog", "know"):
+        for k in ("obs", "actions", "reward", "done", "scores", "status", "groups", "nodes", "health", "rank", "fog", "know", "sight"):
             out[k] = np.array(rec[k])
         assert np.all(out["obs"] == np.round(out["obs"])) and np.abs(out["obs"]).max() <= 500
         return out
@@ -396,13 +410,14 @@ def pack(games, metas, tmax=150):
         scores=np.zeros((G, tmax, 2), np.int32), status=np.zeros((G, tmax), np.uint8),
         groups=np.zeros((G, tmax + 1, 2, NG, 8), np.int16), nodes=np.zeros((G, tmax + 1, NN, 2), np.int16),
         health=np.zeros((G, tmax + 1, 2, NU), np.float64), rank=np.zeros((G, tmax + 1, 2, NG), np.int8),
-        fog=np.zeros((G, tmax + 1, 2, NN), np.uint8), know=np.zeros((G, tmax + 1, 2, NN), np.uint8))
+        fog=np.zeros((G, tmax + 1, 2, NN), np.uint8), know=np.zeros((G, tmax + 1, 2, NN), np.uint8),
+        sight=np.full((G, tmax + 1, 2, NG, 4), -2, np.int8))
     for i, g in enumerate(games):
         T = g["length"]
         d["obs"][i, :T + 1] = g["obs"]
         for k in ("actions", "reward", "done", "scores", "status"):
             d[k][i, :T] = g[k]
-        for k in ("groups", "nodes", "health", "rank", "fog", "know"):
+        for k in ("groups", "nodes", "health", "rank", "fog", "know", "sight"):
             d[k][i, :T + 1] = g[k]
     return d
 

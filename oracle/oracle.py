@@ -90,6 +90,7 @@ def lib():
         L.evo_get_move.argtypes = [C.c_int, C.c_int]
         L.evo_fog_of_war.argtypes = [C.c_void_p, C.c_void_p]
         L.evo_knowledge.argtypes = [C.c_void_p, C.c_void_p]
+        L.evo_sightings.argtypes = [C.c_void_p, C.c_void_p]
         L.evo_scripted_actions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.evo_scripted_reset.argtypes = [C.c_void_p]
         L.evo_episode_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
@@ -190,6 +191,12 @@ class Oracle(object):
     def knowledge(self):
         f = np.zeros((self.n, NP, NN), np.uint8)
         self.L.evo_knowledge(self.h, _p(f))
+        return f
+
+    def sightings(self):
+        """int8 [n][2][12][4]: what observer p knows of opposing group g: seen, node id, destination key (-1 staying), count."""
+        f = np.zeros((self.n, NP, NG, 4), np.int8)
+        self.L.evo_sightings(self.h, _p(f))
         return f
 
     def observe(self):

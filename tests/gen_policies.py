@@ -82,3 +82,22 @@ class NumpyGlobalRandomAgent(object):
         a[:, 0] = np.random.choice(12, 7, replace=False)
         a[:, 1] = np.random.choice(list(range(1, 12)), 7, replace=False)
         return a
+
+
+def sighting_rows(records, rank, types):
+    """Per-group sightings of one observer (int8 [12][4] = seen, node id, destination key, count; oracle / device layout) ->
+    the rows of the reference's `opp_k` dict flattened in ITS iteration order (tests/golden `sight`: node id, destination
+    key, unit type id, count; -2 rows after the last): nodes ascending, destination keys in order of first appearance along
+    the node's group list, groups in list order.  rank[g] = position of opposing group g in its node's list, types[g] its
+    unit type id."""
+    out = np.full((12, 4), -2, np.int8)
+    by_node = {}
+    for g in sorted((g for g in range(12) if records[g][0]), key=lambda g: (int(records[g][1]), int(rank[g]))):
+        by_node.setdefault(int(records[g][1]), {}).setdefault(int(records[g][2]), []).append(g)
+    i = 0
+    for nid in sorted(by_node):
+        for dst, gs in by_node[nid].items():
+            for g in gs:
+                out[i] = (nid, dst, int(types[g]), int(records[g][3]))
+                i += 1
+    return out

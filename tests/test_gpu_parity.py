@@ -32,6 +32,7 @@ def check_state(env, ora_state, what=""):
 
 @pytest.mark.parametrize("fname", TRAJ_FILES + ["edit_annihilation.npz"])
 def test_golden_through_abi(evg, fname):
+    from gen_policies import sighting_rows
     d = load_golden(fname)
     for g in range(len(d["length"])):
         T = int(d["length"][g])
@@ -51,6 +52,10 @@ def test_golden_through_abi(evg, fname):
             assert np.array_equal(s["nodes"][0], d["nodes"][g, t + 1]), ("nodes", fname, g, t)
             assert np.array_equal(_np(env.fog_of_war())[0], d["fog"][g, t + 1]), ("fog-of-war mask", fname, g, t)
             assert np.array_equal(_np(env.knowledge())[0], d["know"][g, t + 1]), ("knowledge levels", fname, g, t)
+            sg = _np(env.sightings())[0]
+            for p in (0, 1):                     # opp_k of build_knowledge_output, captured from the reference's locals
+                assert np.array_equal(sighting_rows(sg[p], d["rank"][g, t + 1, 1 - p], d["obs"][g, t + 1, 1 - p, 46:105:5]),
+                                      d["sight"][g, t + 1, p]), ("sightings", fname, g, t, p)
         env.close()
 
 
@@ -93,7 +98,7 @@ def test_random_rollout_vs_oracle(evg, oracle_mod, N):
         assert np.allclose(_np(rew), o_rew, rtol=0, atol=REWARD_ATOL)
         if t % 25 == 0 or t >= 149:
             check_state(env, ora.get_state(), t)
-            assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.knowledge()), ora.knowledge())
+            assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.knowledge()), ora.knowledge()) and np.array_equal(_np(env.sightings()), ora.sightings())
     st, ost = env.episode_stats(), ora.episode_stats()
     assert np.array_equal(st["totals"], ost["totals"]) and np.array_equal(st["winner"], ost["winner"])
     assert np.array_equal(st["length"], ost["length"]) and np.allclose(st["returns"], ost["returns"], rtol=1e-6, atol=1e-5)

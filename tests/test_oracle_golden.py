@@ -7,6 +7,16 @@ import pytest
 from conftest import load_golden, golden_initial_state, TRAJ_FILES
 
 
+def check_sightings(records, d, g, t):
+    """opp_k of build_knowledge_output (server.py:845-907) as captured from the reference's locals: `records` [2][12][4] are
+    the per-group sightings of both observers."""
+    from gen_policies import sighting_rows
+    for p in (0, 1):
+        want = d["sight"][g, t, p]
+        got = sighting_rows(records[p], d["rank"][g, t, 1 - p], d["obs"][g, t, 1 - p, 46:105:5])
+        assert np.array_equal(got, want), ("opposing-group sightings", g, t, p, got.tolist(), want.tolist())
+
+
 def replay(om, d, g, check_state=True):
     seed, env_id, episode = int(d["seed"][g]), int(d["env_id"][g]), int(d["episode"][g])
     T = int(d["length"][g])
@@ -19,6 +29,7 @@ def replay(om, d, g, check_state=True):
     assert np.array_equal(obs[0], d["obs"][g, 0].astype(np.float64)), "reset obs"
     assert np.array_equal(o.fog_of_war()[0], d["fog"][g, 0]), "fog-of-war mask at reset"
     assert np.array_equal(o.knowledge()[0], d["know"][g, 0]), "knowledge levels at reset"
+    check_sightings(o.sightings()[0], d, g, 0)
     for t in range(T):
         obs, reward, done, info = o.step(d["actions"][g, t][None].astype(np.int32))
         assert np.array_equal(obs[0], d["obs"][g, t + 1].astype(np.float64)), ("obs", g, t)
@@ -34,6 +45,7 @@ def replay(om, d, g, check_state=True):
             assert np.array_equal(s["rank"][0], d["rank"][g, t + 1]), ("node list order", g, t)
             assert np.array_equal(o.fog_of_war()[0], d["fog"][g, t + 1]), ("fog-of-war mask (server.py:402-425)", g, t)
             assert np.array_equal(o.knowledge()[0], d["know"][g, t + 1]), ("knowledge levels (server.py:779-832)", g, t)
+            check_sightings(o.sightings()[0], d, g, t + 1)
     return o
 
 
