@@ -580,3 +580,57 @@ def test_dropin_shares_numpys_global_generator_like_the_reference(evg):
         assert np.array_equal(fin[1], d["final_key"]) and fin[2] == int(d["final_pos"][0])
     finally:
         np.random.set_state(saved)
+
+
+def test_two_million_envs_edges_vs_oracle(evg, oracle_mod):
+    """Size edge: 2^21 + 5 concurrent games in one handle (ragged last wavefront; 4 GB of state, 64-bit offsets into the
+    1.8 GB observation tensor).  The first and the last envs of the range, stepped with the on-device action generator in
+    both the per-turn and the persistent form, equal oracles created for just those global env ids."""
+    import torch
+    N, seed, K = 2 ** 21 + 5, 4242, 48
+    env = evg.EvergladesVecEnv(N, seed=seed, env_id_base=7, auto_reset=True)
+    env.reset()
+    heads = [(0, oracle_mod.Oracle(K, seed=seed, env_id_base=7, auto_reset=True)),
+             (N - K, oracle_mod.Oracle(K, seed=seed, env_id_base=7 + N - K, auto_reset=True))]
+    for _, o in heads:
+        o.reset()
+    for form in (1, 16):
+        env.rollout_random(16, turns_per_launch=form)
+        for first, o in heads:
+            for _ in range(16):
+                a = o.random_actions()
+                o_obs, o_rew, o_done, o_info = o.step(a)
+            sl = slice(first, first + K)
+            assert np.array_equal(_np(env._actions[sl]), a), ("actions", form, first)
+            assert np.array_equal(_np(env.obs[sl]).astype(np.float64), o_obs), ("obs", form, first)
+            assert np.array_equal(_np(env.scores[sl]), o_info["scores"]) and np.allclose(_np(env.reward[sl]), o_rew, rtol=0, atol=REWARD_ATOL)
+    assert int(env.obs[:, 0, 0].min()) == 32 and int(env.obs[:, 0, 0].max()) == 32      # every env is at turn 32
+    env.close()
+    del env
+    torch.cuda.empty_cache()
+
+
+def test_two_handles_on_two_streams(evg, oracle_mod):
+    """Handles are independent: two envs driven from two HIP streams at the same time give what each gives alone."""
+    import torch
+    N = 4096
+    envs = [evg.EvergladesVecEnv(N, seed=s, auto_reset=True) for s in (5, 6)]
+    streams = [torch.cuda.Stream() for _ in envs]
+    torch.cuda.synchronize()
+    for env, st in zip(envs, streams):
+        with torch.cuda.stream(st):
+            env.reset()
+    for _ in range(6):
+        for env, st in zip(envs, streams):
+            with torch.cuda.stream(st):
+                env.rollout_random(10, turns_per_launch=1)
+                env.step(env.random_actions())
+    torch.cuda.synchronize()
+    for env, s in zip(envs, (5, 6)):
+        ora = oracle_mod.Oracle(N, seed=s, auto_reset=True)
+        ora.reset()
+        for _ in range(66):
+            o_obs, _, _, _ = ora.step(ora.random_actions())
+        assert np.array_equal(_np(env.obs).astype(np.float64), o_obs)
+        check_state(env, ora.get_state(), ("stream", s))
+        env.close()
