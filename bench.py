@@ -67,6 +67,26 @@ def pmc_traffic(n_local, turns_per_launch):
     return None, None
 
 
+def cpu_parity(seed, turns, gpu_stats, n=4096):
+    """the CPU restatement plays the same games (same seed, global env ids 0..n-1, same on-device action
+    generator contract) for the same number of turns; the per-env results of the last finished episode and the win
+    counters must equal the GPU's.  Rank 0, outside the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as om
+    om.lib().evo_set_num_threads(usable_cores())
+    o = om.Oracle(n, seed=seed, auto_reset=True)
+    o.reset()
+    for _ in range(turns):
+        o.step_noobs(o.random_actions())
+    st = o.episode_stats()
+    same = (np.array_equal(st["winner"], gpu_stats["winner"][:n]) and np.array_equal(st["length"], gpu_stats["length"][:n]) and
+            np.allclose(st["returns"], gpu_stats["returns"][:n], rtol=0, atol=1e-4))
+    wins = [int((st["winner"] == k).sum()) for k in (0, 1, 2)]
+    gwins = [int((gpu_stats["winner"][:n] == k).sum()) for k in (0, 1, 2)]
+    return {"envs": n, "turns": turns, "equal": bool(same), "cpu_wins_p0_p1_tie": wins, "gpu_wins_p0_p1_tie": gwins}
+
+
 def cpu_baseline(seed, budget_s=12.0):
     """The CPU oracle (C port of the reference's turn loop, oracle/evg_oracle.c) timed on this box's host
     cores with OpenMP over envs: same workload (random vs random incl. action generation and observations,
@@ -234,6 +254,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed)
+            if args.workload == "random" and turn_counter <= 1500:
+                out["cpu_baseline"]["same_games_as_gpu"] = cpu_parity(args.seed, turn_counter, st)
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:
