@@ -118,3 +118,20 @@ def test_shard_range_partitions(evg):
         for (s0, c0), (s1, _) in zip(spans, spans[1:]):
             assert s0 + c0 == s1
     assert evg.shard_range(524288, 8, 3) == (3 * 65536, 65536)
+
+
+def test_plain_c_client_builds_and_fails_loudly_without_a_device():
+    """examples/c_client.c compiles with gcc against include/evg.h alone; on a box without a gfx950 device the library
+    refuses to create a handle (no CPU fallback) and the client reports the ABI's error text."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build_c_client()
+    exe = os.path.join(g.ROOT, "examples", "c_client")
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: covered by the gpu tests")
+    except ImportError:
+        pass
+    out = subprocess.run([exe, "8", "2", "1"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "no HIP device" in out.stderr

@@ -634,3 +634,29 @@ def test_two_handles_on_two_streams(evg, oracle_mod):
         assert np.array_equal(_np(env.obs).astype(np.float64), o_obs)
         check_state(env, ora.get_state(), ("stream", s))
         env.close()
+
+
+def test_plain_c_client_of_the_abi(evg):
+    """examples/c_client.c (gcc, no Python, no torch: include/evg.h + hipMalloc'ed buffers) plays the same games as the
+    Python binding: same win counters and the same checksum over the last observations."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_client")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build_c_client()
+    N, turns, seed = 1000, 320, 77
+    out = subprocess.run([exe, str(N), str(turns), str(seed)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    f = out.stdout.split()
+    got = {f[i]: int(f[i + 1]) for i in range(0, len(f), 2)}
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    env.reset()
+    for _ in range(turns):
+        env.step(env.random_actions())
+    tot = env.episode_stats()["totals"]
+    o = _np(env.obs).astype(np.int64).reshape(-1)
+    chk = int((o * (1 + np.arange(o.size) % 7)).sum())
+    assert (got["episodes"], got["p0"], got["p1"], got["tie"]) == tuple(int(x) for x in tot) and got["episodes"] >= 2 * N
+    assert got["obs_checksum"] == chk
+    env.close()
