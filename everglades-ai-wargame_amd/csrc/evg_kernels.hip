@@ -148,12 +148,14 @@ __device__ __forceinline__ void cycle_advance(int& group_num, int& node_num) {
 
 template <class View>
 __device__ __forceinline__ void agent_rows(int policy, const View& v, const DevTables* T, uint32_t seed_lo, uint32_t seed_hi, uint32_t env_id,
-                                           uint32_t episode, int player, bool commit, uint32_t* p_cycle, uint32_t* p_swarm, uint32_t* p_dfs, int2 (&rows)[NA]) {
-    // `commit` is false for the padding lanes of a partial last workgroup: they compute like everyone else but must not
-    // advance the agent state of the env their indices are clamped to
+                                           uint32_t episode, int player, bool commit, bool active, uint32_t* p_cycle, uint32_t* p_swarm, uint32_t* p_dfs, int2 (&rows)[NA]) {
+    // `commit` is false for the padding lanes of a partial last workgroup (they compute like everyone else but must not
+    // advance the agent state of the env their indices are clamped to) and for a finished, not yet reset game: the harness
+    // has left that game's loop (evaluate.py:147-152), its agents are not consulted -- zero rows, state untouched
     const int turn = v.turn();
 #pragma unroll
     for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 0);                   // np.zeros(shape)
+    if (!active) return;
     // cycling state shared by most bots: first_turn << 8 | group_num << 4 | node_num | strat_index << 9 | agentNumber==2 << 13
     const uint32_t cst = *p_cycle;
     int first = (int)((cst >> 8) & 1u), group_num = (int)((cst >> 4) & 15u), node_num = (int)(cst & 15u);
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         } else {                                        // on-device scripted agents of both seats (evg_rollout_policies, fused)
             const ChipView<LPW> view{&L, col, E, P, turn, p1nib};
             const size_t ai = (size_t)P * N + e;
-            agent_rows(P ? io.policy1 : io.policy0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, valid,
+            agent_rows(P ? io.policy1 : io.policy0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, valid, status == 0,
                        S.agent_cycle + ai, S.agent_swarm + ai, S.agent_dfs + ai, act);
         }
         if (valid && io.actions_out) {
@@ -1095,7 +1097,7 @@ __global__ void __launch_bounds__(256) evg_scripted_actions_kernel(DevState S, i
     const size_t ai = (size_t)player * S.N + e;
     const ObsView<OT> v{obs + ((size_t)e * 2 + player) * OBS};
     int2 rows[NA];
-    agent_rows(policy, v, S.T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, S.episode[e], player, true, S.agent_cycle + ai, S.agent_swarm + ai,
+    agent_rows(policy, v, S.T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, S.episode[e], player, true, ((S.env[e] >> 8) & 3u) == 0u, S.agent_cycle + ai, S.agent_swarm + ai,
                S.agent_dfs + ai, rows);
     int2* out = reinterpret_cast<int2*>(actions) + ((size_t)e * 2 + player) * NA;
 #pragma unroll

@@ -135,3 +135,13 @@ def test_plain_c_client_builds_and_fails_loudly_without_a_device():
         pass
     out = subprocess.run([exe, "8", "2", "1"], capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "no HIP device" in out.stderr
+
+
+def test_normal_confidence_interval_matches_scipy(evg):
+    """evaluate.py prints statsmodels' proportion_confint(..., 'normal'): p +- z_{1-alpha/2} sqrt(p(1-p)/n), clipped."""
+    from scipy.stats import norm
+    for count, n, alpha in ((37, 100, 0.05), (0, 50, 0.05), (999, 1000, 0.05), (512, 1024, 0.1), (3, 7, 0.01)):
+        q = count / n
+        half = norm.ppf(1 - alpha / 2) * np.sqrt(q * (1 - q) / n)
+        lo, hi = evg.proportion_confint_normal(count, n, alpha)
+        assert abs(lo - max(0.0, q - half)) < 1e-8 and abs(hi - min(1.0, q + half)) < 1e-8

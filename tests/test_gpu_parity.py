@@ -660,3 +660,44 @@ def test_plain_c_client_of_the_abi(evg):
     assert (got["episodes"], got["p0"], got["p1"], got["tie"]) == tuple(int(x) for x in tot) and got["episodes"] >= 2 * N
     assert got["obs_checksum"] == chk
     env.close()
+
+
+def test_evaluate_harness_matches_sequential_semantics(evg, oracle_mod):
+    """everglades_amd.evaluate(): the reference's evaluation loop (evaluate.py:127-181) batched -- E consecutive episodes
+    per env, agent objects alive across them, an agent is not consulted once its game is over, seat-0 win bookkeeping.
+    The oracle plays the same harness loop game by game; winners must agree env by env, for native bots on both seats
+    (fused persistent rollout) and for a host-side policy callable on seat 0."""
+    import torch
+    N, E, seed = 96, 3, 21
+    for p0, p1 in (("cycle_rush_turn25", "swarm"), ("cycle_target_node11P2", "base_rush_v1"), ("dfs_attack", "bull_rush")):
+        res = evg.evaluate(p0, p1, N * E, num_envs=N, seed=seed)
+        ora = oracle_mod.Oracle(N, seed=seed, auto_reset=False)
+        i0, i1 = evg._lib.POLICY_NAMES.index(p0), evg._lib.POLICY_NAMES.index(p1)
+        want = []
+        for ep in range(E):
+            obs = ora.reset()
+            for t in range(150):
+                a = np.zeros((N, 2, 7, 2), np.int32)
+                ora.scripted_actions(i0, 0, obs, a)
+                ora.scripted_actions(i1, 1, obs, a)
+                obs, _, done, _ = ora.step(a)
+                if done.all():
+                    break
+            want.append(ora.episode_stats()["winner"].copy())
+        want = np.stack(want)
+        assert np.array_equal(res["winners"], want), (p0, p1)
+        assert res["games"] == N * E and res["wins"] == int((want == 0).sum()) and res["ties"] == int((want == 2).sum())
+        lo, hi = res["confint"]
+        assert 0.0 <= lo <= res["win_rate"] <= hi <= 1.0
+
+    # a host-side policy on seat 0: the same orders as the native bot, computed from the observation tensor by the device
+    # helper -- the generic per-turn path of evaluate() must give the fused path's result
+    helper = evg.EvergladesVecEnv(N, seed=seed, auto_reset=False)
+
+    def same_commands(obs):
+        return torch.tensor([[i + 1, i + 1] for i in range(7)], dtype=torch.int32, device=obs.device).expand(N, 7, 2)
+
+    a = evg.evaluate(same_commands, "swarm", N, num_envs=N, seed=seed)
+    b = evg.evaluate("same_commands", "swarm", N, num_envs=N, seed=seed)
+    assert np.array_equal(a["winners"], b["winners"]) and a["mean_length"] == b["mean_length"]
+    helper.close()
