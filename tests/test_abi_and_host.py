@@ -145,3 +145,19 @@ def test_normal_confidence_interval_matches_scipy(evg):
         half = norm.ppf(1 - alpha / 2) * np.sqrt(q * (1 - q) / n)
         lo, hi = evg.proportion_confint_normal(count, n, alpha)
         assert abs(lo - max(0.0, q - half)) < 1e-8 and abs(hi - min(1.0, q + half)) < 1e-8
+
+
+def test_ctypes_mirror_has_the_c_layout(evg, tmp_path):
+    """The ctypes structures of _lib.py against the compiler's view of include/evg.h: sizes and the offsets that matter."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "evg.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %d\\n", sizeof(evg_config), '
+                   'sizeof(evg_tables), offsetof(evg_config, tables), offsetof(evg_config, rng_mode), offsetof(evg_tables, node_defense), '
+                   'offsetof(evg_tables, max_turns), EVG_ABI_VERSION); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    L = evg._lib
+    want = [C.sizeof(L.EvgConfig), C.sizeof(L.EvgTables), L.EvgConfig.tables.offset, L.EvgConfig.rng_mode.offset, L.EvgTables.node_defense.offset,
+            L.EvgTables.max_turns.offset, L.ABI_VERSION]
+    assert got == want
