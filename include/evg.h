@@ -189,6 +189,8 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream);
  * behaviour); their random draws (np.random.choice, np.random.shuffle, random.random) are keyed like every other
  * draw.  Order ids a bot emits outside [0, 11] (e.g. the -1 of cycle_target_node*.py) are passed
  * through; evg_step treats them like the reference's Python lists do.
+ * An agent is not consulted for a game that is over and not yet reset (status != 0 without auto-reset): the harness has left
+ * that game's loop (evaluate.py:147-152), so its rows are zero and its object does not advance.
  * evg_scripted_reset re-creates all agent objects (first_turn, cycling position, attack list). */
 enum {
     EVG_POLICY_RANDOM = 0,                 /* random_actions.py, random_actions_2.py                         */
