@@ -1171,30 +1171,66 @@ __global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* fog, 
 // ---------------------------------------------------------------------------------------------
 // 'smart state' preprocessing of agents/Smart_State/DQNAgent.py:200-300: obs[N][2][105] of one player
 // -> features float32 [N][12][59] (the reference builds float64 and the network casts to float32: computed in f64,
-// rounded once).  One thread per output element: fully coalesced stores; the obs row is read through L1/L2.
+// rounded once).
 // ---------------------------------------------------------------------------------------------
 template <typename OT>
 __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player, const OT* obs, float* out) {
-    constexpr int F = 59;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)N * NG * F) return;
-    const int f = (int)(idx % F), sw = (int)((idx / F) % NG);
-    const size_t e = idx / ((size_t)F * NG);
-    const OT* o = obs + (e * 2 + player) * OBS;
-    double v = 0.0;
-    if (f == 0) v = (double)o[0] / 150.0;                                             // :280
-    else if (f < 12) v = (double)o[3 + 4 * (f - 1)] / 100.0;                          // :282
-    else if (f < 23) v = (double)o[4 + 4 * (f - 12)] / 100.0;                         // :284
-    else if (f < 34) {                                                                // :200-213, :286
-        int cnt = 0;
+    // One wavefront per env and pass.  The 105-value observation row is staged in LDS once; every distinct output value of the
+    // env goes into a small per-wave table -- the 34 features all swarms share and the 12 per-swarm health features are
+    // one IEEE f64 division each (46 lanes: one division sequence per env instead of one per output element), then the
+    // 12 in-transit flags, the constants 0 and 1 and the 12 x 11 one-hot node entries -- and the env's 12 x 59 floats
+    // are streamed out as table[idx] in 64-float (256-byte) coalesced stores; idx depends only on the position in the
+    // row and is computed once per lane.  HBM-bound by the 2 832 B written per env.
+    constexpr int F = 59, WPB = 4, NIT = (NG * F + 63) / 64;
+    constexpr int T_HP = 34, T_MOV = 46, T_ZERO = 58, T_ONE = 59, T_HOT = 64, T_SIZE = T_HOT + NG * NN;
+    __shared__ int   row[WPB][128];
+    __shared__ float tab[WPB][T_SIZE + 4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t idx[NIT];
 #pragma unroll
-        for (int k = 0; k < NG; ++k) cnt += ((int)o[48 + 5 * k] == 0 && (int)o[45 + 5 * k] - 1 == f - 23) ? 1 : 0;
-        v = (double)cnt / 12.0;
-    } else if (f < 45) v = ((int)o[45 + 5 * sw] == f - 34 + 1) ? 1.0 : 0.0;           // :288-292
-    else if (f == 45) v = (double)o[47 + 5 * sw] * (double)o[49 + 5 * sw] / 1000.0;   // :294
-    else if (f == 46) v = (double)o[48 + 5 * sw];                                     // :296
-    else v = (f - 47 == sw) ? 1.0 : 0.0;                                              // :298
-    out[idx] = (float)v;
+    for (int i = 0; i < NIT; ++i) {
+        const int j = lane + 64 * i, sw = j / F, f = j - sw * F;
+        idx[i] = (uint8_t)(f < 34 ? f : (f < 45 ? T_HOT + sw * NN + (f - 34) : (f == 45 ? T_HP + sw : (f == 46 ? T_MOV + sw : (f - 47 == sw ? T_ONE : T_ZERO)))));
+    }
+    if (lane == 0) { tab[w][T_ZERO] = 0.f; tab[w][T_ONE] = 1.f; }
+    const int passes = (N + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
+    for (int ps = 0; ps < passes; ++ps) {
+        const long long e = ((long long)ps * gridDim.x + blockIdx.x) * WPB + w;
+        const bool live = e < N;
+        const OT* o = obs + ((size_t)(live ? e : 0) * 2 + player) * OBS;
+        row[w][lane] = live ? (int)o[lane] : 0;                              // every observation value is an integer
+        row[w][lane + 64] = (live && lane + 64 < OBS) ? (int)o[lane + 64] : 0;
+        __syncthreads();
+        const int* r = row[w];
+        double num = 0.0, den = 1.0;
+        if (lane == 0) { num = (double)r[0]; den = 150.0; }                                          // :280
+        else if (lane < 12) { num = (double)r[3 + 4 * (lane - 1)]; den = 100.0; }                    // :282
+        else if (lane < 23) { num = (double)r[4 + 4 * (lane - 12)]; den = 100.0; }                   // :284
+        else if (lane < 34) {                                                                       // :200-213, :286
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) cnt += (r[48 + 5 * k] == 0 && r[45 + 5 * k] - 1 == lane - 23) ? 1 : 0;
+            num = (double)cnt; den = 12.0;
+        } else if (lane < 46) {                                                                     // :294, swarm lane - 34
+            const int sw = lane - 34;
+            num = (double)r[47 + 5 * sw] * (double)r[49 + 5 * sw]; den = 1000.0;
+        }
+        if (lane < 46) tab[w][lane] = (float)(num / den);
+        if (lane < NG) tab[w][T_MOV + lane] = (float)r[48 + 5 * lane];                                // :296
+#pragma unroll
+        for (int t = lane; t < NG * NN; t += 64) {                                                    // :288-292
+            const int sw = t / NN, n = t - sw * NN;
+            tab[w][T_HOT + t] = (r[45 + 5 * sw] == n + 1) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (live) {
+            float* dst = out + (size_t)e * NG * F;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                if (lane + 64 * i < NG * F) dst[lane + 64 * i] = tab[w][idx[i]];                      // one-hot swarm id (:298) = the two constants
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1267,8 +1303,8 @@ int launch_scripted_reset(const DevState& S, void* stream) {
 }
 
 int launch_smart_state(const DevState& S, int player, const void* obs, float* out, int obs_dtype, void* stream) {
-    const size_t total = (size_t)S.N * NG * 59;
-    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    const int blocks = (S.N + 3) / 4;                       // one wavefront per env and pass; 8 blocks per CU resident, further envs in passes
+    const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (obs_dtype) {
         case EVG_OBS_F32: hipLaunchKernelGGL(evg_smart_state_kernel<float>, grid, block, 0, s, S.N, player, (const float*)obs, out); break;

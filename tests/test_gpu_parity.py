@@ -405,6 +405,21 @@ def test_smart_state_features_match_reference_fixture(evg):
         env.close()
 
 
+def test_smart_state_multi_pass_ragged_vs_oracle(evg, oracle_mod):
+    """The feature kernel at a size that needs several passes of its resident grid and is not a multiple of its 4 envs per
+    block, on mid-game observations of both seats: equal to float32(oracle float64)."""
+    N = 3 * 8192 + 4099
+    env = evg.EvergladesVecEnv(N, seed=8, auto_reset=True)
+    env.reset()
+    env.rollout_random(70, turns_per_launch=70)
+    obs = _np(env.obs).astype(np.float64)
+    for p in range(2):
+        got = _np(env.smart_state(p))
+        want = oracle_mod.smart_state(obs[:, p]).astype(np.float32)
+        assert got.shape == (N, 12, 59) and np.array_equal(got, want), p
+    env.close()
+
+
 @pytest.mark.parametrize("tpl", [2, 7, 150])
 def test_persistent_multi_turn_rollout_equals_stepwise(evg, oracle_mod, tpl):
     """The persistent rollout form (each launch plays `tpl` consecutive turns per wavefront with the state resident on
