@@ -292,9 +292,11 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     evg_handle* h = new evg_handle();
     h->cfg = *cfg;
     if (const char* ab = getenv("EVG_ABLATE")) h->ablate = (uint32_t)strtoul(ab, nullptr, 0);
+    const char* force_div = getenv("EVG_FORCE_IEEE_DIV");      // test hook: run the kernel's true-division branch
     if (const char* ln = getenv("EVG_LANES")) h->lanes = atoi(ln) == 32 ? 32 : 64;
     int rc = build_dev_tables(cfg, &h->host_tables);
     if (rc != EVG_OK) { delete h; return rc; }
+    if (force_div && atoi(force_div) != 0) h->host_tables.fast_div = 0;
     const size_t N = (size_t)cfg->num_envs;
     DevState& S = h->S;
     memset(&S, 0, sizeof(S));

@@ -716,3 +716,57 @@ def test_evaluate_harness_matches_sequential_semantics(evg, oracle_mod):
     b = evg.evaluate("same_commands", "swarm", N, num_envs=N, seed=seed)
     assert np.array_equal(a["winners"], b["winners"]) and a["mean_length"] == b["mean_length"]
     helper.close()
+
+
+def _custom_tables(evg, oracle_mod):
+    """A table set that differs from DemoMap / UnitDefinitions in every runtime table: distances, control points, node
+    defenses (non-dyadic), resources, unit stats.  Returns (device tables, oracle tables) with identical contents."""
+    import ctypes as C
+    t = evg.default_tables()
+    conn = {1: {2: 5, 4: 7}, 2: {1: 5, 3: 3, 5: 6}, 3: {2: 3, 4: 2, 5: 4, 6: 5, 7: 4}, 4: {1: 7, 3: 2, 7: 6},
+            5: {2: 6, 3: 4, 8: 3, 9: 7}, 6: {3: 5, 9: 2}, 7: {3: 4, 4: 6, 9: 3, 10: 5}, 8: {5: 3, 9: 6, 11: 4},
+            9: {5: 7, 6: 2, 7: 3, 8: 6, 10: 1}, 10: {7: 5, 9: 1, 11: 7}, 11: {8: 4, 10: 7}}
+    for a in range(12):
+        for b in range(12):
+            t.node_dist[a][b] = conn.get(a, {}).get(b, 0)
+    for i, (cp, dfn, res) in enumerate([(300, 0.7, 0), (60, 1.3, 2), (120, 2.9, 0), (45, 0.35, 1), (100, 1.15, 2), (80, 3.3, 0), (100, 0.05, 1),
+                                        (75, 1.7, 0), (110, 2.45, 2), (50, 0.9, 1), (280, 1.1, 0)], start=1):
+        t.node_control_points[i], t.node_defense[i], t.node_resource[i] = cp, dfn, res
+    for u, (h, d, s, c, k) in enumerate([(5, 1, 2, 3, 2), (3, 2, 1, 1, 3), (2, 3, 3, 2, 1)]):
+        t.unit_health[u], t.unit_damage[u], t.unit_speed[u], t.unit_control[u], t.unit_cost[u] = h, d, s, c, k
+    t.max_turns = 97
+    ot = oracle_mod.Tables()
+    assert C.sizeof(ot) == C.sizeof(t)
+    C.memmove(C.byref(ot), C.byref(t), C.sizeof(t))
+    return t, ot
+
+
+@pytest.mark.parametrize("force_ieee_div", [False, True])
+def test_custom_tables_vs_oracle(evg, oracle_mod, monkeypatch, force_ieee_div):
+    """Every runtime table changed (map distances, control points, non-dyadic defenses, resources, unit stats, turn limit):
+    brawl and random play with auto-reset stay bit-equal to the oracle built from the same tables -- once with the exact
+    table-reciprocal quotient (validated per table set at evg_create) and once with the kernel's true-division branch
+    forced (EVG_FORCE_IEEE_DIV, a test hook)."""
+    from gen_policies import policy_actions
+    if force_ieee_div:
+        monkeypatch.setenv("EVG_FORCE_IEEE_DIV", "1")
+    t, ot = _custom_tables(evg, oracle_mod)
+    N, seed = 224, 31
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, tables=t)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True, tables=ot)
+    obs = _np(env.reset()).astype(np.float64)
+    assert np.array_equal(obs, ora.reset())
+    rng = np.random.default_rng(2)
+    for tt in range(230):
+        a = policy_actions("brawl", obs, tt, rng) if (tt // 40) % 2 == 0 else _np(env.random_actions()).copy()
+        o, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(a)
+        obs = _np(o).astype(np.float64)
+        assert np.array_equal(obs, o_obs), ("obs", tt)
+        assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(info["status"]), o_info["status"])
+        assert np.array_equal(_np(done), o_done) and np.allclose(_np(rew), o_rew, rtol=0, atol=REWARD_ATOL)
+        if tt % 46 == 45:
+            check_state(env, ora.get_state(), tt)
+            assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.sightings()), ora.sightings())
+    assert env.episode_stats()["totals"][0] >= 2 * N
+    env.close()
