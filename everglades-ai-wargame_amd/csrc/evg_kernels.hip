@@ -316,30 +316,44 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const DevTables* T = S.T;
 
     STAMP(0);
-    // ---- constant tables: adjacency and combat denominators to LDS (indexed per lane), the rest into scalar registers
-    if (lane < 12) {
-        L.adj[lane] = T->adj_row[lane];
-    }
-    if (lane < 48) {
-        L.den[lane] = (&T->den_tab[0][0])[lane];
-        L.rcp[lane] = (&T->rcp_tab[0][0])[lane];
-    }
-
-    // ---- load state (env fastest; the two player rows of a group index interleave across lanes)
+    // ---- prologue loads: constant tables (adjacency and combat denominators go to LDS, indexed per lane; the rest is read
+    // into scalar registers where used) and this lane's state (env fastest; the two player rows of a group index interleave
+    // across lanes).  Every load is issued before the first LDS store, so the launch pays ONE memory round trip here
+    // instead of one per table and one for the state.
+    const uint64_t adj_v = T->adj_row[lane < 12 ? lane : 0];
+    const double den_v = (&T->den_tab[0][0])[lane < 48 ? lane : 0], rcp_v = (&T->rcp_tab[0][0])[lane < 48 ? lane : 0];
     const uint32_t envw = S.env[e];
-    int turn = (int)(envw & 0xFFu);
-    int status = (int)((envw >> 8) & 3u);
     uint32_t episode = S.episode[e];
-    uint32_t st[3];
+    uint32_t st[3], g_in[12], n_in[6];
 #pragma unroll
     for (int j = 0; j < 3; ++j) st[j] = S.stamp[(size_t)(P * 3 + j) * N + e];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) g_in[k] = S.grp[(size_t)(P * 12 + k) * N + e];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                       // player 0 lane: nodes 1..6, player 1 lane: nodes 7..11
+        const int n = P ? 7 + j : 1 + j;
+        n_in[j] = S.node[(size_t)((n <= NN ? n : NN) - 1) * N + e];
+    }
+    // caller-supplied orders (evg_step): this player's 7 rows are part of the same round trip
+    int2 act_in[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) act_in[i] = make_int2(0, 0);
+    if (!MULTI && !io.gen_actions && io.actions) {
+        const int2* ap = reinterpret_cast<const int2*>(io.actions) + ((size_t)e * 2 + P) * NA;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) act_in[i] = ap[i];
+    }
+    int turn = (int)(envw & 0xFFu);
+    int status = (int)((envw >> 8) & 3u);
+    if (lane < 12) L.adj[lane] = adj_v;
+    if (lane < 48) { L.den[lane] = den_v; L.rcp[lane] = rcp_v; }
     if (envlane) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) L.G[k][lane] = S.grp[(size_t)(P * 12 + k) * N + e];
+        for (int k = 0; k < 12; ++k) L.G[k][lane] = g_in[k];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {                   // player 0 lane: nodes 1..6, player 1 lane: nodes 7..11
+        for (int j = 0; j < 6; ++j) {
             const int n = P ? 7 + j : 1 + j;
-            if (n <= NN) L.NW[n][E] = S.node[(size_t)(n - 1) * N + e];
+            if (n <= NN) L.NW[n][E] = n_in[j];
         }
     }
     __syncthreads();
@@ -374,8 +388,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const uint64_t cst_n = P ? T->cost_nib[1] : T->cost_nib[0];
     const uint64_t typ_n = P ? T->type_nib[1] : T->type_nib[0];
     const int max_turns = T->max_turns;
-    // this player's 7 order rows: read from the caller's tensor (issued now, used after the barrier), or -- in the
-    // fused random-vs-random rollout -- drawn here by the same generator as evg_random_actions and written out
+    // this player's 7 order rows: read from the caller's tensor (in the prologue), or -- in the fused rollouts -- produced
+    // here by the same generators as evg_random_actions / evg_scripted_actions and written out
     int2 act[NA];
     if (io.gen_actions) {
         if (io.gen_actions == 1) {
@@ -392,9 +406,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int i = 0; i < NA; ++i) ao[i] = act[i];
         }
     } else {
-        const int2* ap = reinterpret_cast<const int2*>(io.actions) + ((size_t)e * 2 + P) * NA;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) act[i] = io.actions ? ap[i] : make_int2(0, 0);
+        for (int i = 0; i < NA; ++i) act[i] = act_in[i];             // loaded in the prologue (single-turn form only)
     }
     STAMP(1);
 
