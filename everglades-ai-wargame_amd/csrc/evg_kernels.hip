@@ -324,6 +324,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const double den_v = (&T->den_tab[0][0])[lane < 48 ? lane : 0], rcp_v = (&T->rcp_tab[0][0])[lane < 48 ? lane : 0];
     const uint32_t envw = S.env[e];
     uint32_t episode = S.episode[e];
+    float ep_ret = S.ep_ret[(size_t)P * N + e];         // this player's running episode return: a register across the launch's turns
     uint32_t st[3], g_in[12], n_in[6];
 #pragma unroll
     for (int j = 0; j < 3; ++j) st[j] = S.stamp[(size_t)(P * 3 + j) * N + e];
@@ -334,6 +335,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int n = P ? 7 + j : 1 + j;
         n_in[j] = S.node[(size_t)((n <= NN ? n : NN) - 1) * N + e];
     }
+    // fused scripted agents: this seat's agent object (three words) lives in registers across the launch's turns
+    uint32_t ag_cycle = 0, ag_swarm = 0, ag_dfs = 0;
+    const size_t ai = (size_t)P * N + e;
+    if (io.gen_actions == 2) { ag_cycle = S.agent_cycle[ai]; ag_swarm = S.agent_swarm[ai]; ag_dfs = S.agent_dfs[ai]; }
     // caller-supplied orders (evg_step): this player's 7 rows are part of the same round trip
     int2 act_in[NA];
 #pragma unroll
@@ -396,9 +401,12 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             gen_random_rows(S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, turn, P, act);
         } else {                                        // on-device scripted agents of both seats (evg_rollout_policies, fused)
             const ChipView<LPW> view{&L, col, E, P, turn, p1nib};
-            const size_t ai = (size_t)P * N + e;
-            agent_rows(P ? io.policy1 : io.policy0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, valid, status == 0,
-                       S.agent_cycle + ai, S.agent_swarm + ai, S.agent_dfs + ai, act);
+            agent_rows(P ? io.policy1 : io.policy0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, true, status == 0,
+                       &ag_cycle, &ag_swarm, &ag_dfs, act);
+            if (valid && (!MULTI || iter == nturns - 1)) {      // padding lanes of a partial last workgroup never write
+                const size_t ai_ = (size_t)P * N + e;
+                S.agent_cycle[ai_] = ag_cycle; S.agent_swarm[ai_] = ag_swarm; S.agent_dfs[ai_] = ag_dfs;
+            }
         }
         if (valid && io.actions_out) {
             int2* ao = reinterpret_cast<int2*>(io.actions_out) + ((size_t)e * 2 + P) * NA;
@@ -855,14 +863,15 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // ---------------- episode bookkeeping + auto-reset (each lane keeps its own player's return)
     bool do_reset = false;
     if (play) {
-        float r = S.ep_ret[(size_t)P * N + e] + (P ? rew1 : rew0);
+        float r = ep_ret + (P ? rew1 : rew0);
         if (done) {
             S.fin_ret[(size_t)e * 2 + P] = r;
             if (P == 0) { S.fin_len[e] = turn; S.fin_win[e] = (int8_t)winner; }
             if (S.auto_reset) { do_reset = true; r = 0.f; }
         }
-        S.ep_ret[(size_t)P * N + e] = r;
+        ep_ret = r;
     }
+    if (valid && !observe_only && (!MULTI || iter == nturns - 1)) S.ep_ret[(size_t)P * N + e] = ep_ret;
     {
         const bool fin = play && done && P == 0;
         const uint64_t mf = __ballot(fin);
