@@ -770,3 +770,28 @@ def test_custom_tables_vs_oracle(evg, oracle_mod, monkeypatch, force_ieee_div):
             assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.sightings()), ora.sightings())
     assert env.episode_stats()["totals"][0] >= 2 * N
     env.close()
+
+
+def test_long_soak_persistent_vs_oracle(evg, oracle_mod):
+    """Twenty consecutive auto-reset episodes (3 000 turns) of the full 65 536-env batch in the persistent form: a 320-env
+    window in the middle of the range stays bit-equal to the oracle after every episode (observations, orders, episode
+    results), and the batch-wide win counters add up."""
+    N, seed, K, first = 65536, 606, 320, 40000
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    env.reset()
+    ora = oracle_mod.Oracle(K, seed=seed, env_id_base=first, auto_reset=True)
+    ora.reset()
+    sl = slice(first, first + K)
+    for ep in range(20):
+        env.rollout_random(150, turns_per_launch=150)
+        for _ in range(150):
+            a = ora.random_actions()
+            o_obs, _, _, _ = ora.step(a)
+        assert np.array_equal(_np(env.obs[sl]).astype(np.float64), o_obs), ("obs", ep)
+        assert np.array_equal(_np(env._actions[sl]), a), ("orders", ep)
+        st, ost = env.episode_stats(), ora.episode_stats()
+        assert np.array_equal(st["winner"][sl], ost["winner"]) and np.array_equal(st["length"][sl], ost["length"]), ep
+        assert np.allclose(st["returns"][sl], ost["returns"], rtol=0, atol=1e-4)
+    tot = env.episode_stats()["totals"]
+    assert tot[0] == tot[1] + tot[2] + tot[3] and tot[0] >= 20 * N
+    env.close()
