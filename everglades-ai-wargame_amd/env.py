@@ -160,7 +160,13 @@ class EvergladesEnv(object):
         return observations, reward, d, {}
 
     def render(self, mode="human"):
-        raise NotImplementedError("rendering (everglades_renderer.py) is outside the accelerated path")
+        """evaluate.py:133-134 calls env.render() on every step by default; the pyglet renderer (everglades_renderer.py) is
+        outside the accelerated path, so this is a no-op that says so once instead of breaking the harness loop."""
+        if not getattr(self, "_render_warned", False):
+            self._render_warned = True
+            import warnings
+            warnings.warn("everglades_amd.EvergladesEnv.render(): rendering is not part of the accelerated path; ignored")
+        return None
 
     def close(self):
         pass

@@ -161,3 +161,14 @@ def test_ctypes_mirror_has_the_c_layout(evg, tmp_path):
     want = [C.sizeof(L.EvgConfig), C.sizeof(L.EvgTables), L.EvgConfig.tables.offset, L.EvgConfig.rng_mode.offset, L.EvgTables.node_defense.offset,
             L.EvgTables.max_turns.offset, L.ABI_VERSION]
     assert got == want
+
+
+def test_render_is_a_warning_noop(evg):
+    """evaluate.py calls env.render() on every step by default: the drop-in must not break that loop."""
+    import warnings
+    env = evg.EvergladesEnv()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert env.render() is None and env.render(mode="human") is None
+    assert len(w) == 1 and "not part of the accelerated path" in str(w[0].message)
+    env.close()
