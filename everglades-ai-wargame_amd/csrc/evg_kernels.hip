@@ -62,6 +62,8 @@ struct __align__(16) StepLds {
     } u;
     uint64_t adj[12];
     double   den[48], rcp[48];           // DevTables::den_tab / rcp_tab (indexed per lane)
+    int32_t  cp[12], ts[12], res[12];    // control points, team start, resource bits by node ID
+    uint64_t nib[10];                    // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24
 };
 
 // 12-input sorting network (tools/gen_sort12.py: 42 compare-exchanges, verified with the 0-1 principle)
@@ -321,6 +323,15 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // across lanes).  Every load is issued before the first LDS store, so the launch pays ONE memory round trip here
     // instead of one per table and one for the state.
     const uint64_t adj_v = T->adj_row[lane < 12 ? lane : 0];
+    const int l12 = lane < 12 ? lane : 0;
+    const int32_t cp_v = T->control_points[l12], ts_v = T->team_start[l12], res_v = T->resource[l12];
+    uint64_t nib_v = 0;
+    if (lane == 0) nib_v = T->p1map_nib;
+    else if (lane < 3) nib_v = T->speed_nib[lane - 1];
+    else if (lane < 5) nib_v = T->control_nib[lane - 3];
+    else if (lane < 7) nib_v = T->cost_nib[lane - 5];
+    else if (lane < 9) nib_v = T->type_nib[lane - 7];
+    else if (lane == 9) nib_v = (uint64_t)(uint32_t)T->max_turns | ((uint64_t)(T->damage_nib & 0xFFFFu) << 8) | ((uint64_t)(T->fast_div ? 1u : 0u) << 24);
     const double den_v = (&T->den_tab[0][0])[lane < 48 ? lane : 0], rcp_v = (&T->rcp_tab[0][0])[lane < 48 ? lane : 0];
     const uint32_t envw = S.env[e];
     uint32_t episode = S.episode[e];
@@ -350,7 +361,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     int turn = (int)(envw & 0xFFu);
     int status = (int)((envw >> 8) & 3u);
-    if (lane < 12) L.adj[lane] = adj_v;
+    if (lane < 12) { L.adj[lane] = adj_v; L.cp[lane] = cp_v; L.ts[lane] = ts_v; L.res[lane] = res_v; }
+    if (lane < 10) L.nib[lane] = nib_v;
     if (lane < 48) { L.den[lane] = den_v; L.rcp[lane] = rcp_v; }
     if (envlane) {
 #pragma unroll
@@ -387,12 +399,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const bool valid = envlane && E < nvalid;
     const int e = valid ? e0 + E : e0;
     const size_t N = (size_t)S.N;
-    const uint64_t p1nib = T->p1map_nib;
-    const uint64_t spd_n = P ? T->speed_nib[1] : T->speed_nib[0];
-    const uint64_t ctl_n = P ? T->control_nib[1] : T->control_nib[0];
-    const uint64_t cst_n = P ? T->cost_nib[1] : T->cost_nib[0];
-    const uint64_t typ_n = P ? T->type_nib[1] : T->type_nib[0];
-    const int max_turns = T->max_turns;
+    const uint64_t p1nib = L.nib[0];
+    const uint64_t spd_n = L.nib[1 + P], ctl_n = L.nib[3 + P], cst_n = L.nib[5 + P], typ_n = L.nib[7 + P];
+    const uint32_t misc = (uint32_t)L.nib[9];
+    const int max_turns = (int)(misc & 0xFFu);
     // this player's 7 order rows: read from the caller's tensor (in the prologue), or -- in the fused rollouts -- produced
     // here by the same generators as evg_random_actions / evg_scripted_actions and written out
     int2 act[NA];
@@ -539,8 +549,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int excl_i = excl & 0xFFFF, excl_d = excl >> 16, tot_i = tot & 0xFFFF, tot_d = tot >> 16, mid_i = mid & 0xFFFF, mid_d = mid >> 16;
         // the pool holds every fight of the wave in the common case; otherwise two passes of 16 envs each
         const int npass = tot_d <= DP_CAP ? 1 : 2;
-        const uint32_t dmg_nib = T->damage_nib;
-        const bool fast_div = T->fast_div != 0;
+        const uint32_t dmg_nib = (misc >> 8) & 0xFFFFu;
+        const bool fast_div = ((misc >> 24) & 1u) != 0;
         for (int ps = 0; ps < npass; ++ps) {
             const bool inpass = npass == 1 || (lane / (LPW / 2)) == ps;     // helper lanes own no items
             const int ref_i = (npass == 2 && ps == 1) ? mid_i : 0, ref_d = (npass == 2 && ps == 1) ? mid_d : 0;
@@ -605,7 +615,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             const int SL = lane | side;
                             const uint32_t fso = L.u.c.FS[node][SL ^ 1];
                             const uint32_t tot_o = fso >> 16, doff_o = fso & 0xFFFFu;
-                            const uint64_t tn_s = side ? T->type_nib[1] : T->type_nib[0];
+                            const uint64_t tn_s = L.nib[7 + side];
                             int last = -1;
                             for (;;) {
                                 int best = 256, bg = -1, bcnt = 0;
@@ -634,7 +644,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const int node = (int)((sp >> 12) & 15u), cnt = __popc(sp & 0xFFFu);
                 const uint32_t fso = L.u.c.FS[node][SL ^ 1];
                 const uint32_t tot_o = fso >> 16, doff_o = fso & 0xFFFFu;
-                const uint64_t tn_s = side ? T->type_nib[1] : T->type_nib[0];
+                const uint64_t tn_s = L.nib[7 + side];
                 const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
                 const uint32_t dmg = (dmg_nib >> (4 * type)) & 15u;
                 const int turn_e = (int)L.u.c.TURN[SL];
@@ -691,7 +701,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             h[8] = h[9] = h[10] = h[11] = 0.0;
                         }
                     }
-                    const uint64_t tn_s = side ? T->type_nib[1] : T->type_nib[0];
+                    const uint64_t tn_s = L.nib[7 + side];
                     const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
                     const int ctrl_by = (int)((L.NW[node][SL >> 1] >> 10) & 3u) - 1;
                     const int di = (int)type * 12 + (ctrl_by == side ? node : 0);                    // :592-597 (fort bonus dead)
@@ -794,8 +804,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             a0v[j] = L.u.A[n][col & ~1];
             a1v[j] = L.u.A[n][col | 1];
             nwv[j] = L.NW[n][E];
-            cpv[j] = P ? T->control_points[(7 + j) % 12] : T->control_points[1 + j];
-            tsv[j] = P ? T->team_start[(7 + j) % 12] : T->team_start[1 + j];
+            cpv[j] = L.cp[n];
+            tsv[j] = L.ts[n];
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -923,7 +933,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         orow[0] = (int16_t)turn;
 #pragma unroll
         for (int i = 1; i <= NN; ++i) {
-            const int res = P ? T->resource[(int)((p1nib >> (4 * i)) & 15u)] : T->resource[i];
+            const int res = L.res[P ? (int)((p1nib >> (4 * i)) & 15u) : i];
             int16_t* o = orow + 1 + 4 * (i - 1);
             o[0] = (res & EVG_RES_DEFENSE) ? 1 : 0;                                // :442
             o[1] = (res & EVG_RES_OBSERVE) ? 1 : 0;                                // :443
