@@ -676,12 +676,19 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const uint32_t mask = sp & 0xFFFu;
                 const uint32_t doff = L.u.c.FS[node][SL] & 0xFFFFu;
                 const uint32_t base = (sp >> 16) & 0xFFu;
+                // the group's alive units are consecutive target indices, so their damage bytes are one run of <= 12 bytes in the
+                // pool starting at byte `run0` (<= 15 bytes with the misalignment: four words, read at once)
+                const uint32_t run0 = doff * 4u + base, w0i = run0 >> 2, sh0 = run0 & 3u;
+                uint32_t dw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dw[q] = L.u.c.DP[min(w0i + (uint32_t)q, (uint32_t)(DP_CAP - 1))];
+                const uint64_t dlo = (uint64_t)dw[0] | ((uint64_t)dw[1] << 32), dhi = (uint64_t)dw[2] | ((uint64_t)dw[3] << 32);
                 uint32_t dmv[12], any = 0;
 #pragma unroll
                 for (int sl = 0; sl < 12; ++sl) {            // rank of slot sl among the alive slots: no dependent chain, no branches
-                    const uint32_t idx = base + (uint32_t)__popc(mask & ((1u << sl) - 1u));
-                    const uint32_t wd = L.u.c.DP[min(doff + (idx >> 2), (uint32_t)(DP_CAP - 1))];
-                    dmv[sl] = ((mask >> sl) & 1u) ? ((wd >> (8 * (idx & 3u))) & 0xFFu) : 0u;
+                    const uint32_t b = sh0 + (uint32_t)__popc(mask & ((1u << sl) - 1u));               // byte of the run, 0..14
+                    const uint32_t v = (uint32_t)((b < 8u ? dlo : dhi) >> (8u * (b & 7u))) & 0xFFu;
+                    dmv[sl] = ((mask >> sl) & 1u) ? v : 0u;
                     any |= dmv[sl];
                 }
                 if (any) {
