@@ -637,6 +637,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                 }
             } else {
+            const uint32_t seed_lo = S.seed_lo, seed_hi = S.seed_hi, id_base = S.env_id_base + (uint32_t)e0;
             for (int it = lane; it < nitems; it += WG) {
                 const uint32_t item = L.u.c.W[it];
                 const int SL = (int)(item & 63u), gid = (int)(item >> 6), side = SL & 1;
@@ -648,9 +649,9 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
                 const uint32_t dmg = (dmg_nib >> (4 * type)) & 15u;
                 const int turn_e = (int)L.u.c.TURN[SL];
-                const uint32_t epi_e = L.u.c.EPI[SL], env_id_e = S.env_id_base + (uint32_t)(e0 + (SL >> 1));
+                const uint32_t epi_e = L.u.c.EPI[SL], env_id_e = id_base + (uint32_t)(SL >> 1);
                 for (int b = 0; b * 4 < cnt; ++b) {
-                    const uint4 x = rng_block(S.seed_lo, S.seed_hi, env_id_e, epi_e, RNG_COMBAT, (uint32_t)b, turn_e, node, side, gid);
+                    const uint4 x = rng_block(seed_lo, seed_hi, env_id_e, epi_e, RNG_COMBAT, (uint32_t)b, turn_e, node, side, gid);
                     const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -869,22 +870,34 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         rew0 = (float)((double)score[0] / (double)EVG_MAX_SCORE);
         rew1 = (float)((double)score[1] / (double)EVG_MAX_SCORE);
     }
-    if (valid && !observe_only && P == 0) {
-        reinterpret_cast<float2*>(io.reward)[e] = make_float2(rew0, rew1);
-        io.done[e] = done ? 1 : 0;
-        if (io.winner) io.winner[e] = (int8_t)winner;
-        if (io.scores) reinterpret_cast<int2*>(io.scores)[e] = make_int2(score[0], score[1]);
-        if (io.status) io.status[e] = (uint8_t)status;
+    {
+        // the output pointers are fetched together (one scalar-load batch), not one by one inside the branches below
+        float* const p_reward = io.reward;
+        uint8_t* const p_done = io.done;
+        int8_t* const p_winner = io.winner;
+        int32_t* const p_scores = io.scores;
+        uint8_t* const p_status = io.status;
+        if (valid && !observe_only && P == 0) {
+            reinterpret_cast<float2*>(p_reward)[e] = make_float2(rew0, rew1);
+            p_done[e] = done ? 1 : 0;
+            if (p_winner) p_winner[e] = (int8_t)winner;
+            if (p_scores) reinterpret_cast<int2*>(p_scores)[e] = make_int2(score[0], score[1]);
+            if (p_status) p_status[e] = (uint8_t)status;
+        }
     }
 
     // ---------------- episode bookkeeping + auto-reset (each lane keeps its own player's return)
     bool do_reset = false;
+    float* const p_fin_ret = S.fin_ret;
+    int32_t* const p_fin_len = S.fin_len;
+    int8_t* const p_fin_win = S.fin_win;
+    const int auto_reset = S.auto_reset;
     if (play) {
         float r = ep_ret + (P ? rew1 : rew0);
         if (done) {
-            S.fin_ret[(size_t)e * 2 + P] = r;
-            if (P == 0) { S.fin_len[e] = turn; S.fin_win[e] = (int8_t)winner; }
-            if (S.auto_reset) { do_reset = true; r = 0.f; }
+            p_fin_ret[(size_t)e * 2 + P] = r;
+            if (P == 0) { p_fin_len[e] = turn; p_fin_win[e] = (int8_t)winner; }
+            if (auto_reset) { do_reset = true; r = 0.f; }
         }
         ep_ret = r;
     }
