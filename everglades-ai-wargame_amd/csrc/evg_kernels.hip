@@ -63,6 +63,7 @@ struct __align__(16) StepLds {
     uint64_t adj[12];
     double   den[48], rcp[48];           // DevTables::den_tab / rcp_tab (indexed per lane)
     int32_t  cp[12], ts[12], res[12];    // control points, team start, resource bits by node ID
+    uint32_t init_grp[24], init_node[12];   // state right after game_init (auto-reset inside the kernel)
     uint64_t nib[10];                    // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24
 };
 
@@ -324,6 +325,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // instead of one per table and one for the state.
     const uint64_t adj_v = T->adj_row[lane < 12 ? lane : 0];
     const int l12 = lane < 12 ? lane : 0;
+    const uint32_t ig_v = T->init_grp[lane < 24 ? lane : 0], in_v = T->init_node[l12];
     const int32_t cp_v = T->control_points[l12], ts_v = T->team_start[l12], res_v = T->resource[l12];
     uint64_t nib_v = 0;
     if (lane == 0) nib_v = T->p1map_nib;
@@ -363,6 +365,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int status = (int)((envw >> 8) & 3u);
     if (lane < 12) { L.adj[lane] = adj_v; L.cp[lane] = cp_v; L.ts[lane] = ts_v; L.res[lane] = res_v; }
     if (lane < 10) L.nib[lane] = nib_v;
+    if (lane < 24) L.init_grp[lane] = ig_v;
+    if (lane < 12) L.init_node[lane] = in_v;
     if (lane < 48) { L.den[lane] = den_v; L.rcp[lane] = rcp_v; }
     if (envlane) {
 #pragma unroll
@@ -923,11 +927,11 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int j = 0; j < 3; ++j) st[j] = 0;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) gw[k] = P ? T->init_grp[12 + k] : T->init_grp[k];
+        for (int k = 0; k < 12; ++k) gw[k] = L.init_grp[P * 12 + k];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int n = P ? 7 + j : 1 + j;
-            if (n <= NN) L.NW[n][E] = P ? T->init_node[(7 + j) % 12] : T->init_node[1 + j];
+            if (n <= NN) L.NW[n][E] = L.init_node[n];
         }
     }
     __syncthreads();        // node words final; everybody is done adding to A
