@@ -6,11 +6,20 @@
 One "step" = one pass of the hot path over one batch: on-device random action generation for both
 players of every env (the input generator, agents/State_Machine/random_actions.py) + the fused
 env-step kernel (game_turn + observations + rewards, auto-reset on).  Inputs and outputs stay in HBM.
+
+Window.  Before anything is timed (and whatever --warmup says) the batch is brought to a DESYNCHRONISED
+steady state: during a 150-turn pre-roll env e is restarted at pre-roll turn e mod 150, so afterwards the
+episode phases of the batch are spread uniformly over 0..149 and every timed turn sees the episode-average
+mix of early (few fights) and late (many fights) positions, with ~1/150 of the envs resetting per turn.
+A K-step timed window of any length therefore measures the same thing.
+
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); environments shard by
 contiguous global id (weak scaling: 65 536 per GPU) and the only collective is the gather of episode
-results at episode boundaries (RCCL all-gather over xGMI).  Rank 0 prints ONE JSON line.
+results (RCCL all-gather over xGMI).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -21,8 +30,16 @@ sys.path.insert(0, ROOT)
 
 # algorithmic bytes per env-step = read + write of the 1 780 B state
 # (health f64[2][100] 1 600 + groups 144 + nodes 33 + turn/status 2) + actions 112 + obs f32 840 + 18.
-ALGO_BYTES_PER_ENV_STEP = 4530
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Kept as a NAMED secondary figure only: the kernel does not move these bytes (the state stays on chip in the
+# persistent form and health rows are touched only where combat hits), so it is not the roofline numerator.
+SURVEY_ALGO_BYTES_PER_ENV_STEP = 4530
+# What one env-step MUST write/read with this layout: observations f32 2x105x4 = 840, orders 2x7x2xi32 = 112,
+# reward 8 + done 1 + winner 1 + scores 8 + status 1 = 19  ->  971 B, plus the float64 health rows of the groups
+# that were hit (64 B read + 64 B written per group row, 96 for group 11) -- see DESIGN.md section 3.
+MANDATORY_OUTPUT_BYTES = {"float32": 971, "float64": 971 + 840, "int16": 971 - 420}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMD-32, one wave64 VALU instruction per 2 cycles, 2.4 GHz
+PHASES = 150                 # episode length of random vs random (server.py:321): the pre-roll spreads phases over it
 
 
 def usable_cores():
@@ -44,53 +61,73 @@ def usable_cores():
     return n
 
 
-def pmc_traffic(n_local, turns_per_launch):
-    """HBM bytes per TURN of the step kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
-    2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md, calibrated in the same passes).
-    Counters cannot be read live from inside this process, so the newest committed figure for this config and launch
-    form is reported; None when there is none."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    for f in reversed(files):
+def kernel_source_hash():
+    """Identifies the kernel sources the running libevg.so was built from (build() rebuilds it from them): the committed
+    counter passes under profiles/ carry the same hash, and figures from another build are not used."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "evg.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(kind, n_local, workload, obs_dtype):
+    """Newest committed counter summary (profiles/*_<kind>.json: tools/pmc_summary.py / tools/sq_summary.py) of THIS build
+    (same kernel-source hash), batch size, workload and observation dtype; None when there is none.  Counters cannot be read
+    from inside the benchmarked process, so the bench prices its own launches with the per-env-step figures of those passes."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s.json" % kind)), reverse=True):
         try:
             d = json.load(open(f))
-            if int(d.get("envs", -1)) != n_local:
-                continue
-            forms = d.get("forms")
-            if forms:
-                form = forms["persistent"] if turns_per_launch > 1 else forms["one_launch_per_turn"]
-                return float(form["corrected_bytes_per_turn"]), os.path.relpath(f, ROOT)
-            if turns_per_launch == 1:
-                return float(d["corrected_bytes_per_launch"]), os.path.relpath(f, ROOT)
         except Exception:
             continue
-    return None, None
+        if d.get("kernel_source_hash") == kernel_source_hash() and int(d.get("envs", -1)) == n_local and \
+                d.get("workload", "random") == workload and d.get("obs_dtype", "float32") == obs_dtype:
+            d["_file"] = os.path.relpath(f, ROOT)
+            return d
+    return None
 
 
-def cpu_parity(seed, turns, gpu_stats, n=4096):
+def desynchronise(env, first_id, workload, rollout):
+    """150 turns, one launch per turn; after turn j the envs with global id = j (mod 150) start a new episode."""
+    import torch
+    ids = torch.arange(first_id, first_id + env.num_envs, device=env.device, dtype=torch.int64)
+    for j in range(PHASES):
+        rollout(1, False, 1)
+        env.reset(mask=((ids % PHASES) == j).to(torch.uint8))
+
+
+def cpu_parity(seed, n, steps_after_preroll, gpu_stats, gpu_state):
     """the CPU restatement plays the same games (same seed, global env ids 0..n-1, same on-device action
-    generator contract) for the same number of turns; the per-env results of the last finished episode and the win
-    counters must equal the GPU's.  Rank 0, outside the timed region."""
+    generator contract, same desynchronising pre-roll) for the same number of turns; the per-env results of the last finished
+    episode, the win counters and the whole final state (groups, nodes, float64 health) must equal the GPU's, for EVERY env
+    of rank 0's shard.  Outside the timed region."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as om
     om.lib().evo_set_num_threads(usable_cores())
     o = om.Oracle(n, seed=seed, auto_reset=True)
     o.reset()
-    for _ in range(turns):
+    ids = np.arange(n)
+    for j in range(PHASES):
+        o.step_noobs(o.random_actions())
+        o.reset(mask=(ids % PHASES == j).astype(np.uint8))
+    for _ in range(steps_after_preroll):
         o.step_noobs(o.random_actions())
     st = o.episode_stats()
     same = (np.array_equal(st["winner"], gpu_stats["winner"][:n]) and np.array_equal(st["length"], gpu_stats["length"][:n]) and
-            np.allclose(st["returns"], gpu_stats["returns"][:n], rtol=0, atol=1e-4))
+            np.allclose(st["returns"], gpu_stats["returns"][:n], rtol=0, atol=1e-4) and np.array_equal(st["totals"], gpu_stats["totals"]))
+    os_ = o.get_state()
+    state_same = all(np.array_equal(os_[k], gpu_state[k][:n]) for k in ("groups", "nodes", "health", "env"))
     wins = [int((st["winner"] == k).sum()) for k in (0, 1, 2)]
     gwins = [int((gpu_stats["winner"][:n] == k).sum()) for k in (0, 1, 2)]
-    return {"envs": n, "turns": turns, "equal": bool(same), "cpu_wins_p0_p1_tie": wins, "gpu_wins_p0_p1_tie": gwins}
+    return {"envs": n, "turns": PHASES + steps_after_preroll, "equal": bool(same and state_same), "episode_results_equal": bool(same),
+            "final_state_equal_incl_float64_health": bool(state_same), "cpu_wins_p0_p1_tie": wins, "gpu_wins_p0_p1_tie": gwins}
 
 
 def cpu_baseline(seed, budget_s=12.0):
     """The CPU oracle (C port of the reference's turn loop, oracle/evg_oracle.c) timed on this box's host
-    cores with OpenMP over envs: same workload (random vs random incl. action generation and observations,
-    auto-reset), bounded sample."""
+    cores with OpenMP over envs: same workload (random vs random incl. action generation and float64 observations --
+    the reference's dtype --, auto-reset), bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ctypes as C
     import numpy as np
@@ -118,7 +155,7 @@ def cpu_baseline(seed, budget_s=12.0):
         dt = time.perf_counter() - t0
         if (dt >= budget_s and turns % 150 == 0) or dt >= 2.5 * budget_s:
             break
-    return dict(value=n * turns / dt, unit="env-steps/s", cores=cores, kind="port",
+    return dict(value=n * turns / dt, unit="env-steps/s", cores=cores, kind="port", obs_dtype="float64",
                 sample="%d envs x %d turns (random vs random, action generation + step + f64 observations, auto-reset), "
                        "C oracle with OpenMP over envs; the Python reference itself runs 529-554 env-steps/s on one core "
                        "(BASELINE.md, measured in the build container)" % (n, turns))
@@ -133,12 +170,14 @@ def main():
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--obs-dtype", default="float32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the one-launch-per-turn and float64-observation legs (profiling runs)")
     ap.add_argument("--turns-per-launch", type=int, default=150,
                     help="consecutive turns each wavefront plays per launch of the step kernel (persistent rollout form; "
                          "1 = one launch per turn). Outputs are written every turn in both forms and the results are identical.")
     ap.add_argument("--workload", default="random", choices=["random", "scripted"],
                     help="random: BASELINE metric config (random vs random); scripted: BASELINE config 5 (cycle_rush_turn25 vs swarm)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -171,10 +210,6 @@ def main():
     total = n_local * world
     first, cnt = evg.shard_range(total, world, rank)
     assert cnt == n_local
-    env = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed, env_id_base=first, obs_dtype=args.obs_dtype, auto_reset=True)
-    env.reset()
-    stats_dev = env.episode_stats_device()
-    period = 150                                   # episode length of random vs random: gather at episode boundaries
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -182,60 +217,117 @@ def main():
             dist.barrier(device_ids=[dev_index]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(device)
 
-    def run(nsteps, timed, tpl=None):
-        """nsteps turns through the native rollout driver (evg_rollout_random / evg_rollout_policies: launches of the step
-        kernel with the agents of both seats fused in, enqueued from C on torch's current stream), split at multiples of 150
-        turns (the episode length of random vs random) where the episode results are gathered.  Returns the summed
-        step-kernel time in ms (HIP events recorded on that stream around the step-kernel launches) and the last gather."""
-        tpl = args.turns_per_launch if tpl is None else tpl
-        nonlocal turn_counter
-        kernel_ms_sum, gathered = 0.0, None
-        left = nsteps
-        while left > 0:
-            chunk = min(left, period - turn_counter % period)
-            out = (env.rollout_random(chunk, time_kernel=timed, turns_per_launch=tpl) if args.workload == "random" else
-                   env.rollout_policies(chunk, "cycle_rush_turn25", "swarm", time_kernel=timed, fused=True, turns_per_launch=tpl))
-            if timed:
-                kernel_ms_sum += out[-1] * chunk
-            turn_counter += chunk
-            left -= chunk
-            if turn_counter % period == 0:
-                gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
-        return kernel_ms_sum, gathered
+    def make_env(obs_dtype):
+        """A handle in the desynchronised steady state + its rollout function (nsteps, timed, turns per launch) -> kernel ms sum."""
+        env = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed, env_id_base=first, obs_dtype=obs_dtype, auto_reset=True, library=args.library)
+        env.reset()
 
-    turn_counter = 0
-    run(args.warmup, False)
+        def rollout(nsteps, timed, tpl):
+            """nsteps turns through the native rollout driver (evg_rollout_random / evg_rollout_policies: launches of the step
+            kernel with the agents of both seats fused in, enqueued from C on torch's current stream).  Returns the summed
+            step-kernel time in ms (HIP events recorded on that stream around the step-kernel launches)."""
+            out = (env.rollout_random(nsteps, time_kernel=timed, turns_per_launch=tpl) if args.workload == "random" else
+                   env.rollout_policies(nsteps, "cycle_rush_turn25", "swarm", time_kernel=timed, fused=True, turns_per_launch=tpl))
+            return out[-1] * nsteps if timed else 0.0
 
-    # ---- timed region: exactly K steps
+        desynchronise(env, first, args.workload, rollout)
+        rollout(PHASES, True, args.turns_per_launch)          # settle: one more episode length in the launch form that is timed (also creates its timing events)
+        return env, rollout
+
+    env, rollout = make_env(args.obs_dtype)
+    stats_dev = env.episode_stats_device()
+    played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
+    if args.warmup > 0:
+        rollout(args.warmup, True, args.turns_per_launch)
+        played += args.warmup
+
+    # ---- timed region: exactly K steps, the gather of episode results included
     barrier()
     t0 = time.perf_counter()
-    kernel_ms_sum, gathered = run(args.steps, True)
+    kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch)
+    gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    played += args.steps
+    dt = dt_local
+    per_rank = None
     if world > 1:
-        tmax = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt_local, kernel_ms_sum / args.steps], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "seconds": float(t[0]), "env_steps_per_s": n_local * args.steps / float(t[0]), "kernel_ms_per_step": float(t[1])}
+                    for r, t in enumerate(allr)]
+        dt = max(p["seconds"] for p in per_rank)
     step_kernel_ms = kernel_ms_sum / args.steps
+    st = env.episode_stats()
+    final_state = env.get_state() if (world == 1 and not args.no_cpu_baseline and args.workload == "random" and played <= 2000) else None
 
-    # for reference, outside the timed region: the same rollout with one launch per turn (what env.step() costs per call)
-    per_turn_launch = None
-    if args.turns_per_launch > 1 and world == 1:
-        barrier()
-        t1 = time.perf_counter()
-        k1, _ = run(150, True, tpl=1)
-        barrier()
-        d1 = time.perf_counter() - t1
-        per_turn_launch = {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": k1 / 150}
+    # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
+    # reference's own observation dtype (float64)
+    per_turn_launch = obs_f64 = None
+    if world == 1 and not args.no_extra_legs:
+        if args.turns_per_launch > 1:
+            rollout(16, True, 1)                               # warms the single-turn instantiation and creates its events
+            barrier()
+            t1 = time.perf_counter()
+            k1 = rollout(150, True, 1)
+            barrier()
+            d1 = time.perf_counter() - t1
+            per_turn_launch = {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": k1 / 150,
+                               "kernel_ms_is": "mean of the step-kernel launches bracketed by HIP events (every 8th)"}
+        if args.obs_dtype != "float64":
+            env64, rollout64 = make_env("float64")
+            rollout64(8, True, args.turns_per_launch)
+            barrier()
+            t1 = time.perf_counter()
+            k64 = rollout64(150, True, args.turns_per_launch)
+            barrier()
+            d64 = time.perf_counter() - t1
+            obs_f64 = {"env_steps_per_s": total * 150 / d64, "ms_per_step": d64 / 150 * 1e3, "kernel_ms": k64 / 150, "turns_per_launch": args.turns_per_launch}
+            env64.close()
 
     if rank == 0:
         value = total * args.steps / dt
-        achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9
-        st = env.episode_stats()
         tpl = args.turns_per_launch
-        # the committed PMC passes are of the random-vs-random workload
-        traffic_turn, traffic_src = pmc_traffic(n_local, tpl) if args.workload == "random" else (None, None)
-        traffic = traffic_turn * tpl if traffic_turn else None
+        turns_last_launch = args.steps % tpl or min(tpl, args.steps)
+        launches = (args.steps + tpl - 1) // tpl
+        env_steps_per_launch = n_local * args.steps / launches           # mean over the timed launches
+        launch_ms = step_kernel_ms * args.steps / launches
+        pmc = committed_counters("pmc_traffic", n_local, args.workload, args.obs_dtype)
+        sq = committed_counters("sq_counters", n_local, args.workload, args.obs_dtype)
+        mand = MANDATORY_OUTPUT_BYTES[args.obs_dtype]
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms,
+                "kernel_ms_is": "HIP-event launch duration / turns played by the launch", "launches_timed": launches,
+                "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch, "launch_ms": launch_ms,
+                "mandatory_output_bytes_per_env_step": mand,
+                "survey_8d_bytes_per_env_step": SURVEY_ALGO_BYTES_PER_ENV_STEP,
+                "survey_8d_note": "SURVEY 8(d)'s accounting (full state read + write every turn) is NOT what this kernel moves; it is reported "
+                                  "only as survey_8d_rate_GBps and never as the roofline numerator"}
+        roof["survey_8d_rate_GBps"] = SURVEY_ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9
+        if pmc:
+            form = pmc["forms"]["persistent" if tpl > 1 else "one_launch_per_turn"]
+            # steady-state bytes per env-step of the profiled launch shape; the state round trip of a launch (words read at its
+            # start, written at its end) is re-scaled to the turns per launch that were timed here
+            bpe = form["bytes_per_env_step_steady"] + form["state_round_trip_bytes_per_env"] / (args.steps / launches)
+            achieved = bpe * n_local / (step_kernel_ms * 1e-3) / 1e9
+            roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": bpe * env_steps_per_launch, "traffic_unit": "bytes per launch",
+                         "bytes_per_env_step": bpe, "bytes_source": pmc["_file"], "bytes_source_is": "rocprofv3 PMC passes of this build "
+                         "(2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction, calibrated in the same passes), per env-step, times the env-steps of the timed launches",
+                         "ratio_to_mandatory_outputs": bpe / mand, "ratio_survey_8d_to_measured": SURVEY_ALGO_BYTES_PER_ENV_STEP / bpe})
+        else:
+            # no counter pass of this build is committed: price the launches with the bytes they cannot avoid (a LOWER bound on
+            # the traffic, so frac is a lower bound too); traffic stays null
+            achieved = mand * n_local / (step_kernel_ms * 1e-3) / 1e9
+            roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": mand,
+                         "bytes_source": "mandatory outputs only (no committed PMC pass matches kernel_source_hash %s)" % kernel_source_hash()})
+        valu = None
+        if sq:
+            k = sq["kernels"]["persistent" if tpl > 1 else "one_launch_per_turn"]
+            insts = k["valu_insts_per_wave_turn"] * ((n_local + 31) // 32)
+            ach = insts / (step_kernel_ms * 1e-3)
+            valu = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s", "frac": ach / VALU_PEAK_WAVE_INSTS_PER_S,
+                    "valu_insts_per_wave_turn": k["valu_insts_per_wave_turn"], "wave_cycles_per_wave_turn": k.get("wave_cycles_per_wave_turn"),
+                    "source": sq["_file"], "peak_is": "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}
         out = {
             "metric": "env-steps/sec at 65536 concurrent DemoMap games, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -245,25 +337,25 @@ def main():
                                     "step kernel, orders written to an [N,2,7,2] tensor; persistent rollout form, see turns_per_launch), auto-reset, obs %s [N,2,105]" if args.workload == "random" else
                                     "%d concurrent DemoMap games per GPU, on-device Cycle_BRush_Turn25 vs SwarmAgent (BASELINE config 5; both bots fused into the "
                                     "step kernel, orders written out; episodes end by BaseCapture after 84-94 turns), auto-reset, obs %s [N,2,105]") % (n_local, args.obs_dtype),
-                       "envs_per_gpu": n_local, "total_envs": total,
-                       "turns_per_launch": args.turns_per_launch,
-                       "one_launch_per_turn": per_turn_launch, "parallelism": "env-sharded x%d" % world,
+                       "window": "desynchronised steady state: 150-turn pre-roll restarts env e at pre-roll turn e mod 150 (episode phases uniform over 0..149), "
+                                 "then 150 settle turns, --warmup turns and the K timed turns",
+                       "envs_per_gpu": n_local, "total_envs": total, "turns_per_launch": tpl, "turns_of_last_timed_launch": turns_last_launch,
+                       "one_launch_per_turn": per_turn_launch, "obs_float64": obs_f64, "parallelism": "env-sharded x%d" % world,
+                       "kernel_source_hash": kernel_source_hash(),
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
                        "gathered_wins_all_ranks": list(evg.win_counts(gathered)) if gathered is not None else None},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "achieved_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local * tpl, "turns_per_launch": tpl,
-                         "measured_traffic_GBps": (traffic_turn / (step_kernel_ms * 1e-3) / 1e9) if traffic_turn else None,
-                         "note": "achieved uses the ALGORITHMIC bytes of SURVEY 8(d); it exceeds 1.0 of peak when the kernel moves fewer "
-                                 "bytes than that accounting (health rows are only touched where combat hits): compare traffic",
-                         "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms, "kernel_ms_is": "launch duration / turns played by the launch",
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
+            "roofline": roof,
         }
+        if valu:
+            out["roofline_valu_issue"] = valu
+        if world > 1:
+            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "all_gather of [n,4] f32 episode results",
+                                  "per_rank": per_rank}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed)
-            if args.workload == "random" and turn_counter <= 1500:
-                out["cpu_baseline"]["same_games_as_gpu"] = cpu_parity(args.seed, turn_counter, st)
+            if final_state is not None:
+                out["cpu_baseline"]["same_games_as_gpu"] = cpu_parity(args.seed, n_local, played - PHASES, st, final_state)
         print(json.dumps(out), flush=True)
     env.close()
     if world > 1:

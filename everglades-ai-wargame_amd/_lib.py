@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("EVG_LIB_PATH") or os.path.join(HERE, "libevg.so")   # override: diagnostic builds only
+LIB_PATH = os.path.join(HERE, "libevg.so")                # the product library; nothing in the environment changes that
+DIAG_LIB_PATH = os.path.join(HERE, "libevg_diag.so")      # `make -C csrc diag`: phase ablation, 16-envs-per-wave variant, forced IEEE division
+STAMPS_LIB_PATH = os.path.join(HERE, "libevg_stamps.so")  # `make -C csrc stamps`: in-kernel phase stamps (tools/stamps.py)
 
 NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105
 MAX_SCORE = 3700
@@ -47,17 +49,32 @@ class EvgError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libevg.so; fail loudly when it has not been built (there is no fallback path)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise EvgError("libevg.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                       "or `make -C everglades-ai-wargame_amd/csrc`; this package has no CPU fallback" % LIB_PATH)
+def _hip_runtimes_mapped():
+    """Paths of the libamdhip64 images mapped into this process."""
+    found = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if "libamdhip64" in os.path.basename(path):
+                    found.add(os.path.realpath(path))
+    except OSError:
+        pass
+    return sorted(found)
+
+
+def load(path=None):
+    """Load libevg.so (or, for diagnostics, the library at `path`: an explicit argument, never an environment variable);
+    fail loudly when it has not been built (there is no fallback path)."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise EvgError("%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C everglades-ai-wargame_amd/csrc`; this package has no CPU fallback" % path)
     # libevg.so shares streams and device pointers with PyTorch, so both must run on ONE HIP runtime
     # instance: import torch first, so that its libamdhip64.so.7 is the one already in the process when
     # the loader resolves libevg's NEEDED entry of the same SONAME.
@@ -65,7 +82,11 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
+    rts = _hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise EvgError("two HIP runtimes are mapped into this process (%s): torch's stream handles and device pointers would be "
+                       "invalid inside libevg.so -- rebuild libevg.so against the libamdhip64 that torch loads" % ", ".join(rts))
     vp = C.c_void_p
     L.evg_last_error.restype = C.c_char_p
     L.evg_abi_version.restype = C.c_int
@@ -97,11 +118,13 @@ def load():
     L.evg_num_envs.argtypes = [vp]
     L.evg_state_bytes_per_env.argtypes = [vp]
     if L.evg_abi_version() != ABI_VERSION:
-        raise EvgError("libevg.so ABI version %d, binding expects %d" % (L.evg_abi_version(), ABI_VERSION))
-    _lib = L
+        raise EvgError("%s: ABI version %d, binding expects %d" % (path, L.evg_abi_version(), ABI_VERSION))
+    if hasattr(L, "evg_diag_configure"):      # diagnostic libraries only
+        L.evg_diag_configure.argtypes = [vp, C.c_uint32, C.c_int, C.c_int]
+    _libs[path] = L
     return L
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        raise EvgError("libevg error %d: %s" % (rc, load().evg_last_error().decode("utf-8", "replace")))
+        raise EvgError("libevg error %d: %s" % (rc, (lib or load()).evg_last_error().decode("utf-8", "replace")))

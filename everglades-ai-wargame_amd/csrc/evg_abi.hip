@@ -34,6 +34,30 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kGroupSize[NG] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 12};   // everglades_env.py:145-156
 
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it (a process that
+// drives several GPUs, e.g. through torch, must not have its current device changed behind its back).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+#define EVG_ON_DEVICE(h)                                                                                      \
+    DeviceGuard guard_((h)->cfg.device_id);                                                                   \
+    if (guard_.err != hipSuccess) return fail(EVG_ERR_HIP, "selecting device %d failed: %s", (h)->cfg.device_id, hipGetErrorString(guard_.err))
+
 // numpy pairwise order for the cached int(avg health) (server.py:481,491); state import only
 double host_np_sum(const double* h, int n) {
     double s = ((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7]));
@@ -50,10 +74,28 @@ struct evg_handle {
     DevTables* d_tables = nullptr;
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
-    uint32_t ablate = 0;                // EVG_ABLATE (diagnostic)
-    int32_t lanes = 64;                 // step-kernel variant (EVG_LANES=32|64 overrides the default)
-    unsigned long long* stamps = nullptr;   // diagnostic build only
+#ifdef EVG_DIAG                         // diagnostic libraries only, set through evg_diag_configure (never from the environment)
+    uint32_t ablate = 0;
+    int32_t lanes = 64;
+    unsigned long long* stamps = nullptr;
+#endif
 };
+
+// arguments of one step-kernel launch
+static StepIO make_io(const evg_handle* h, const int32_t* actions, void* obs, float* reward, uint8_t* done, int8_t* winner, int32_t* scores,
+                      uint8_t* status, int observe_only, int gen_actions, int policy0, int policy1, int32_t* actions_out) {
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    io.actions = actions; io.obs = obs; io.reward = reward; io.done = done; io.winner = winner; io.scores = scores; io.status = status;
+    io.observe_only = observe_only; io.gen_actions = gen_actions; io.policy0 = policy0; io.policy1 = policy1; io.actions_out = actions_out;
+    io.turns = 1;
+#ifdef EVG_DIAG
+    io.lanes_per_wave = h->lanes; io.ablate = observe_only ? 0u : h->ablate; io.stamps = observe_only ? nullptr : h->stamps;
+#else
+    (void)h;
+#endif
+    return io;
+}
 
 template <typename Tp>
 static int dev_alloc(evg_handle* h, Tp** p, size_t count) {
@@ -144,6 +186,23 @@ static void build_dfs_table(const evg_tables& t, DevTables* D) {
     }
     if (D->dfs_lambda <= 0) { D->dfs_mu = 0; D->dfs_lambda = (int)rows.size(); }     // not reached for connected maps
     for (size_t k = 0; k < rows.size() && k < 192; ++k) D->dfs_rows[k] = rows[k];
+}
+
+// the step kernel's LDS image of the tables it indexes per lane (evg_device.h: LdsTables)
+static void fill_lds_tables(DevTables* D) {
+    LdsTables& L = D->lds;
+    memset(&L, 0, sizeof(L));
+    for (int n = 0; n < 12; ++n) {
+        L.adj[n] = D->adj_row[n];
+        L.cp[n] = D->control_points[n]; L.ts[n] = D->team_start[n]; L.res[n] = D->resource[n];
+        L.init_node[n] = D->init_node[n];
+    }
+    for (int i = 0; i < 48; ++i) { L.den[i] = (&D->den_tab[0][0])[i]; L.rcp[i] = (&D->rcp_tab[0][0])[i]; }
+    for (int i = 0; i < 24; ++i) L.init_grp[i] = D->init_grp[i];
+    L.nib[0] = D->p1map_nib;
+    for (int p = 0; p < NP; ++p) { L.nib[1 + p] = D->speed_nib[p]; L.nib[3 + p] = D->control_nib[p]; L.nib[5 + p] = D->cost_nib[p]; L.nib[7 + p] = D->type_nib[p]; }
+    L.nib[9] = (uint64_t)(uint32_t)D->max_turns | ((uint64_t)(D->damage_nib & 0xFFFFu) << 8) | ((uint64_t)(D->fast_div ? 1u : 0u) << 24);
+    memcpy(L.reset_obs, D->reset_obs, sizeof(L.reset_obs));
 }
 
 static int build_dev_tables(const evg_config* cfg, DevTables* D) {
@@ -267,6 +326,7 @@ static int build_dev_tables(const evg_config* cfg, DevTables* D) {
             q[1] = (int16_t)t.group_type[p][g]; q[2] = 100; q[3] = 0; q[4] = (int16_t)kGroupSize[g];
         }
     }
+    fill_lds_tables(D);
     return EVG_OK;
 }
 
@@ -277,6 +337,10 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
         return fail(EVG_ERR_INVALID, "evg_config size/version mismatch (got %u/%u, want %zu/%d)", cfg->struct_size, cfg->abi_version,
                     sizeof(evg_config), EVG_ABI_VERSION);
     if (cfg->num_envs < 1) return fail(EVG_ERR_INVALID, "num_envs must be >= 1");
+    // the random streams are keyed by the 32-bit global env id (csrc/evg_rng.h): ids past 2^32 would alias other envs' streams
+    if (cfg->env_id_base > 0xFFFFFFFFull || cfg->env_id_base + (uint64_t)cfg->num_envs > 0x100000000ull)
+        return fail(EVG_ERR_INVALID, "env_id_base + num_envs = %llu exceeds 2^32 (global env ids are 32-bit keys of the random streams)",
+                    (unsigned long long)(cfg->env_id_base + (uint64_t)cfg->num_envs));
     if (cfg->obs_dtype < EVG_OBS_F32 || cfg->obs_dtype > EVG_OBS_I16) return fail(EVG_ERR_INVALID, "obs_dtype");
     if (cfg->rng_mode != EVG_RNG_KEYED_PHILOX && cfg->rng_mode != EVG_RNG_STOCK_MT19937) return fail(EVG_ERR_INVALID, "rng_mode");
     int ndev = 0;
@@ -291,12 +355,8 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
 
     evg_handle* h = new evg_handle();
     h->cfg = *cfg;
-    if (const char* ab = getenv("EVG_ABLATE")) h->ablate = (uint32_t)strtoul(ab, nullptr, 0);
-    const char* force_div = getenv("EVG_FORCE_IEEE_DIV");      // test hook: run the kernel's true-division branch
-    if (const char* ln = getenv("EVG_LANES")) h->lanes = atoi(ln) == 32 ? 32 : 64;
     int rc = build_dev_tables(cfg, &h->host_tables);
     if (rc != EVG_OK) { delete h; return rc; }
-    if (force_div && atoi(force_div) != 0) h->host_tables.fast_div = 0;
     const size_t N = (size_t)cfg->num_envs;
     DevState& S = h->S;
     memset(&S, 0, sizeof(S));
@@ -307,7 +367,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     S.env_id_base = (uint32_t)cfg->env_id_base;
     rc = dev_alloc(h, &S.grp, 24 * N);
     if (!rc) rc = dev_alloc(h, &S.stamp, 6 * N);
-    if (!rc) rc = dev_alloc(h, &S.node, NN * N);
+    if (!rc) rc = dev_alloc(h, &S.node, 6 * N);
     if (!rc) rc = dev_alloc(h, &S.env, N);
     if (!rc) rc = dev_alloc(h, &S.episode, N);
     if (!rc) rc = dev_alloc(h, &S.health, 2 * NU * N);
@@ -328,7 +388,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (rc) { evg_destroy(h); return rc; }
     S.T = h->d_tables;
 #ifdef EVG_STAMPS
-    if (!rc) rc = dev_alloc(h, &h->stamps, (size_t)((cfg->num_envs + 15) / 16) * 16);
+    rc = dev_alloc(h, &h->stamps, (size_t)((cfg->num_envs + 15) / 16) * 16);
     if (rc) { evg_destroy(h); return rc; }
 #endif
     hipError_t e = hipMemcpy(h->d_tables, &h->host_tables, sizeof(DevTables), hipMemcpyHostToDevice);
@@ -339,11 +399,12 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (e == hipSuccess) e = hipMemset(S.totals, 0, 4 * sizeof(unsigned long long));
     // every env starts in the game_init position; the episode counter is then set to -1 so that the
     // first evg_reset opens episode 0
-    if (e == hipSuccess && launch_reset(S, nullptr, nullptr, cfg->obs_dtype, nullptr) != 0) e = hipGetLastError();
-    if (e == hipSuccess && launch_scripted_reset(S, nullptr) != 0) e = hipGetLastError();
+    // the launchers return the hipError_t of their own launch (0 = success); it is propagated as it is
+    if (e == hipSuccess) e = (hipError_t)launch_reset(S, nullptr, nullptr, cfg->obs_dtype, nullptr);
+    if (e == hipSuccess) e = (hipError_t)launch_scripted_reset(S, nullptr);
     if (e == hipSuccess && mt_key) {
         S.mt_key = mt_key; S.mt_pos = mt_pos;
-        if (launch_mt_seed(S, nullptr, nullptr) != 0) e = hipGetLastError();
+        e = (hipError_t)launch_mt_seed(S, nullptr, nullptr);
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemset(S.episode, 0xFF, N * sizeof(uint32_t));
@@ -365,12 +426,12 @@ int evg_num_envs(const evg_handle* h) { return h ? h->S.N : 0; }
 
 int evg_state_bytes_per_env(const evg_handle* h) {
     (void)h;
-    return 24 * 4 + 6 * 4 + NN * 2 + 4 + 4 + 2 * NU * 8 + 2 * 4;   // grp, stamp, node, env, episode, health, ep_ret
+    return 24 * 4 + 6 * 4 + 6 * 4 + 4 + 4 + 2 * NU * 8 + 2 * 4;   // grp, stamp, node, env, episode, health, ep_ret
 }
 
 int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     const int rc = launch_reset(h->S, mask, obs_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "reset launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -380,8 +441,8 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
              int32_t* scores_out, uint8_t* status_out, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, 0, 0, nullptr, h->stamps, 1, h->lanes, h->ablate};
+    EVG_ON_DEVICE(h);
+    const StepIO io = make_io(h, actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, 0, 0, nullptr);
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -389,8 +450,8 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
 
 int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
-    StepIO io{nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr, nullptr, 1, h->lanes, 0};
+    EVG_ON_DEVICE(h);
+    const StepIO io = make_io(h, nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr);
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -398,7 +459,7 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream) {
 
 int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
     if (!h || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     const int rc = launch_random_actions(h->S, actions_out, stream);
     if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -407,7 +468,7 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
 int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream) {
     if (!h || !obs || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
     if (policy < 0 || policy >= EVG_POLICY_COUNT || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "policy/player out of range");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     const int rc = launch_scripted_actions(h->S, policy, player, obs, actions_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "scripted_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -415,7 +476,7 @@ int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs,
 
 int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void* stream) {
     if (!h || (!fog_out && !knowledge_out)) return fail(EVG_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     const int rc = launch_fog(h->S, fog_out, knowledge_out, nullptr, stream);
     if (rc) return fail(EVG_ERR_HIP, "fog launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -423,7 +484,7 @@ int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void
 
 int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream) {
     if (!h || !sight_out) return fail(EVG_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     const int rc = launch_fog(h->S, nullptr, nullptr, sight_out, stream);
     if (rc) return fail(EVG_ERR_HIP, "sightings launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -431,7 +492,7 @@ int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream) {
 
 int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream) {
     if (!h || !obs || !features_out || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     const int rc = launch_smart_state(h->S, player, obs, features_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -446,7 +507,7 @@ void evg_move_table(int32_t* table /* [11][5] */) {
 
 int evg_scripted_reset(evg_handle* h, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     const int rc = launch_scripted_reset(h->S, stream);
     if (rc) return fail(EVG_ERR_HIP, "scripted_reset launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
@@ -474,7 +535,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
                         uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (steps < 1 || !actions_buf || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, actions_buf, reward_out, done_out required");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipStream_t s_ = s;
     const bool random_pair = policy0 == EVG_POLICY_RANDOM && policy1 == EVG_POLICY_RANDOM;
@@ -490,7 +551,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
             HIP_TRY(hipEventCreate(&ev));
             h->events.push_back(ev);
         }
-        StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, gen_mode, policy0, policy1, actions_buf, h->stamps, 1, h->lanes, h->ablate};
+        StepIO io = make_io(h, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, gen_mode, policy0, policy1, actions_buf);
         int done_turns = 0;
         for (int l = 0; l < nlaunch; ++l) {
             io.turns = steps - done_turns < per_launch ? steps - done_turns : per_launch;
@@ -521,7 +582,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         HIP_TRY(hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    StepIO io{actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? gen_mode : 0, policy0, policy1, actions_buf, h->stamps, 1, h->lanes, h->ablate};
+    const StepIO io = make_io(h, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? gen_mode : 0, policy0, policy1, actions_buf);
     for (int i = 0; i < steps; ++i) {
         int rc = 0;
         if (fused) {
@@ -555,7 +616,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
 int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     const uint32_t* d_seeds = nullptr;
     if (seeds) {                                        // staged in the (about to be overwritten) key array itself: row 623 is written last
         uint32_t* stage = h->S.mt_key + (size_t)(MT_N - 1) * h->S.N;
@@ -571,7 +632,7 @@ int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream) {
 int evg_get_stock_entropy(evg_handle* h, uint32_t* out) {
     if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
     if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t)h->S.N;
     std::vector<uint32_t> k((size_t)MT_N * N), pos(N);
@@ -587,7 +648,7 @@ int evg_get_stock_entropy(evg_handle* h, uint32_t* out) {
 int evg_set_stock_entropy(evg_handle* h, const uint32_t* in) {
     if (!h || !in) return fail(EVG_ERR_INVALID, "null argument");
     if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t)h->S.N;
     std::vector<uint32_t> k((size_t)MT_N * N), pos(N);
@@ -603,7 +664,7 @@ int evg_set_stock_entropy(evg_handle* h, const uint32_t* in) {
 
 int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health, int32_t* env) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t)h->S.N;
     if (groups) {
@@ -622,11 +683,11 @@ int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health
             }
     }
     if (nodes) {
-        std::vector<uint16_t> nd(NN * N);
-        HIP_TRY(hipMemcpy(nd.data(), h->S.node, nd.size() * 2, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> nd(6 * N);
+        HIP_TRY(hipMemcpy(nd.data(), h->S.node, nd.size() * 4, hipMemcpyDeviceToHost));
         for (size_t e = 0; e < N; ++e)
             for (int n = 0; n < NN; ++n) {
-                const uint16_t w = nd[(size_t)n * N + e];
+                const uint32_t w = (nd[(size_t)(n >> 1) * N + e] >> (16 * (n & 1))) & 0xFFFFu;
                 nodes[(e * NN + n) * 2] = (int32_t)(w & 0x3FF) - 512;
                 nodes[(e * NN + n) * 2 + 1] = (int32_t)((w >> 10) & 3) - 1;
             }
@@ -647,11 +708,11 @@ int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health
 int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, const double* health, const int32_t* env) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!groups || !nodes || !health || !env) return fail(EVG_ERR_INVALID, "set_state needs all four arrays");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t)h->S.N;
     std::vector<uint32_t> g(24 * N), st(6 * N, 0u), ev(N), ep(N);
-    std::vector<uint16_t> nd(NN * N);
+    std::vector<uint32_t> nd(6 * N, 0u);
     for (size_t e = 0; e < N; ++e) {
         for (int r = 0; r < 24; ++r) {
             const int32_t* o = groups + (e * 24 + r) * 8;
@@ -673,7 +734,7 @@ int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, co
         for (int n = 0; n < NN; ++n) {
             const int cs = nodes[(e * NN + n) * 2], cb = nodes[(e * NN + n) * 2 + 1];
             if (cs < -511 || cs > 511 || cb < -1 || cb > 1) return fail(EVG_ERR_INVALID, "set_state: env %zu node %d out of domain", e, n + 1);
-            nd[(size_t)n * N + e] = (uint16_t)((cs + 512) | ((cb + 1) << 10));
+            nd[(size_t)(n >> 1) * N + e] |= (uint32_t)((cs + 512) | ((cb + 1) << 10)) << (16 * (n & 1));
         }
         if (env[e * 4] < 0 || env[e * 4] > 255 || env[e * 4 + 1] < 0 || env[e * 4 + 1] > 3) return fail(EVG_ERR_INVALID, "set_state: env %zu turn/status", e);
         ev[e] = (uint32_t)env[e * 4] | ((uint32_t)env[e * 4 + 1] << 8);
@@ -681,7 +742,7 @@ int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, co
     }
     HIP_TRY(hipMemcpy(h->S.grp, g.data(), g.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->S.stamp, st.data(), st.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->S.node, nd.data(), nd.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->S.node, nd.data(), nd.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->S.env, ev.data(), N * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->S.episode, ep.data(), N * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->S.health, health, 2 * NU * N * sizeof(double), hipMemcpyHostToDevice));
@@ -692,7 +753,7 @@ int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, co
 
 int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* winner, int64_t* totals) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t)h->S.N;
     if (returns) HIP_TRY(hipMemcpy(returns, h->S.fin_ret, 2 * N * sizeof(float), hipMemcpyDeviceToHost));
@@ -702,10 +763,31 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
     return EVG_OK;
 }
 
+#ifdef EVG_DIAG
+/* Diagnostic libraries only (libevg_diag.so / libevg_stamps.so; declared in no public header).
+ *   ablate          bit0 orders, bit1 combat, bit2 movement, bit4 observation write-out, bit5 state store are skipped
+ *   lanes_per_wave  64 (default: 32 envs per wavefront) or 32 (16 envs per wavefront + 32 helper lanes)
+ *   force_ieee_div  != 0: run the step kernel's true-division branch although the table set passed the exact-quotient check */
+int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) {
+    if (!h || (lanes_per_wave != 32 && lanes_per_wave != 64)) return fail(EVG_ERR_INVALID, "diag: bad argument");
+    EVG_ON_DEVICE(h);
+    h->ablate = ablate;
+    h->lanes = lanes_per_wave;
+    if (force_ieee_div) {
+        h->host_tables.fast_div = 0;
+        h->host_tables.lds.nib[9] &= ~(1ull << 24);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h->d_tables, &h->host_tables, sizeof(DevTables), hipMemcpyHostToDevice));
+    }
+    return EVG_OK;
+}
+#endif
+
 #ifdef EVG_STAMPS
-/* diagnostic build only: per-workgroup s_memtime stamps of the last step launch, [blocks][16] */
+/* stamps build only: per-workgroup s_memtime stamps of the last step launch, [blocks][16] */
 int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
+    EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->stamps, (size_t)((h->S.N + 15) / 16) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return EVG_OK;

@@ -12,7 +12,8 @@
 //                         destroyed <=> alive mask == 0 (server.py:623-625)
 //   stamp  u32 [6][N]    arrival turn of each group, 4 x u8 per word (group row r -> word r>>2);
 //                         node-list order of the reference == (stamp, gid) order
-//   node   u16 [11][N]   bits 0-9 controlState+512, bits 10-11 controlledBy+1
+//   node   u32 [6][N]    two node words per u32 (word j: node ID 2j+1 in the low half, 2j+2 in the high half), each:
+//                         bits 0-9 controlState+512, bits 10-11 controlledBy+1
 //   env    u32 [N]       bits 0-7 current_turn, bits 8-9 status
 //   episode u32 [N]
 //   health f64 [N][200]  env-major: unitHealth of player p group k at [p*100 + 8k ...]; a group's
@@ -35,7 +36,22 @@ constexpr uint32_t G_DEST_M = 0xFu << G_DEST_S, G_DIST_M = 0x7u << G_DIST_S, G_M
 constexpr uint32_t G_MASK_M = 0xFFFu << G_MASK_S, G_AVG_M = 0x7Fu << G_AVG_S;
 constexpr uint32_t MODE_IDLE = 0, MODE_READY = 1, MODE_MOVING = 2;
 
+// The tables the step kernel indexes per lane, laid out on the host exactly as the kernel keeps them in LDS: one blob,
+// copied by every wavefront with two 16-byte-per-lane loads (13 cache lines shared by the whole grid) instead of a
+// dozen separate table loads.
+struct __attribute__((aligned(16))) LdsTables {
+    uint64_t adj[12];            // nibble j of row i = distance i -> j (0 = not connected)
+    double   den[48], rcp[48];   // DevTables::den_tab / rcp_tab flattened [type][node]
+    int32_t  cp[12], ts[12], res[12];       // control points, team start, resource bits by node ID
+    uint32_t init_grp[24], init_node[12];   // state right after game_init (auto-reset inside the kernel)
+    uint64_t nib[10];            // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24
+    int16_t  reset_obs[2 * OBS]; // observation of the game_init state, both players
+    int16_t  pad_[6];
+};
+static_assert(sizeof(LdsTables) % 16 == 0, "the kernel copies the blob in 16-byte pieces");
+
 struct DevTables {
+    LdsTables lds;               // first member: 16-byte aligned in the device allocation
     uint64_t adj_row[12];        // nibble j of row i = distance i -> j (0 = not connected)
     double   defense[12];
     int32_t  control_points[12];
@@ -69,7 +85,7 @@ struct DevState {
     int32_t   auto_reset;
     uint32_t* grp;
     uint32_t* stamp;
-    uint16_t* node;
+    uint32_t* node;
     uint32_t* env;
     uint32_t* episode;
     double*   health;
@@ -100,10 +116,12 @@ struct StepIO {
                                  // 2: orders of the on-device scripted agents policy0 / policy1 (fused evg_rollout_policies)
     int32_t   policy0, policy1;
     int32_t*  actions_out;       //    ... and store them here ([N][2][7][2], may be NULL)
-    unsigned long long* stamps;  // diagnostic build (EVG_STAMPS) only, else NULL
     int32_t   turns;             // consecutive turns per launch (> 1 only with gen_actions: the fused rollout driver)
+#ifdef EVG_DIAG                  // diagnostic libraries only (libevg_diag.so, libevg_stamps.so)
     int32_t   lanes_per_wave;    // 64: 32 envs per wavefront; 32: 16 envs per wavefront + 32 helper lanes
-    uint32_t  ablate;            // diagnostic: bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
+    uint32_t  ablate;            // bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
+    unsigned long long* stamps;  // EVG_STAMPS only, else NULL
+#endif
 };
 
 // launchers (evg_kernels.hip)

@@ -24,8 +24,15 @@
 
 namespace evg {
 
-// Diagnostic build only (make stamps -> libevg_stamps.so): lane 0 of every wave stores s_memtime at phase
-// boundaries into a debug buffer of its own; the production library contains no stamp.
+// Diagnostics are compiled only into the separate libraries libevg_diag.so (-DEVG_DIAG: phase ablation, the 16-envs-per-wave
+// variant, a switch that forces the IEEE-division branch) and libevg_stamps.so (-DEVG_DIAG -DEVG_STAMPS: lane 0 of every
+// wave stores s_memtime at phase boundaries into a debug buffer of its own).  The product library libevg.so contains
+// none of it: no ablation branch, no stamp, no environment variable.
+#ifdef EVG_DIAG
+#define ABLATED(bit) ((io.ablate & (bit)) != 0u)
+#else
+#define ABLATED(bit) false
+#endif
 #ifdef EVG_STAMPS
 #define STAMP(i)                                                                        \
     do {                                                                                \
@@ -60,12 +67,19 @@ struct __align__(16) StepLds {
         uint32_t A[12][LPW];             // per (own side, node): capture points | units listed << 16
         int16_t  O[LPW * OBS];           // observations of the wave's envs, already in output order [env][player][105]
     } u;
-    uint64_t adj[12];
-    double   den[48], rcp[48];           // DevTables::den_tab / rcp_tab (indexed per lane)
-    int32_t  cp[12], ts[12], res[12];    // control points, team start, resource bits by node ID
-    uint32_t init_grp[24], init_node[12];   // state right after game_init (auto-reset inside the kernel)
-    uint64_t nib[10];                    // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24
+    LdsTables tab;                       // the per-lane-indexed constant tables (evg_device.h), copied from DevTables::lds
 };
+
+// Phase boundary inside the step kernel.  A workgroup is ONE wavefront, and the LDS executes a wavefront's instructions in
+// issue order (so do the vector-memory units, per address), so a boundary needs neither s_barrier nor a wait for outstanding
+// global loads/stores (what __syncthreads() would add: s_waitcnt vmcnt(0) stalls every phase behind the turn's
+// observation and health stores): it only has to keep the COMPILER from moving memory accesses across it.
+#define WAVE_SYNC()                                            \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        asm volatile("" ::: "memory");                         \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
 
 // 12-input sorting network (tools/gen_sort12.py: 42 compare-exchanges, verified with the 0-1 principle)
 #define EVG_SORT12_CES(CE) \
@@ -319,35 +333,23 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const DevTables* T = S.T;
 
     STAMP(0);
-    // ---- prologue loads: constant tables (adjacency and combat denominators go to LDS, indexed per lane; the rest is read
-    // into scalar registers where used) and this lane's state (env fastest; the two player rows of a group index interleave
+    // ---- prologue loads: the constant tables (one blob, already in its LDS layout) and this lane's state (env fastest; the two player rows of a group index interleave
     // across lanes).  Every load is issued before the first LDS store, so the launch pays ONE memory round trip here
     // instead of one per table and one for the state.
-    const uint64_t adj_v = T->adj_row[lane < 12 ? lane : 0];
-    const int l12 = lane < 12 ? lane : 0;
-    const uint32_t ig_v = T->init_grp[lane < 24 ? lane : 0], in_v = T->init_node[l12];
-    const int32_t cp_v = T->control_points[l12], ts_v = T->team_start[l12], res_v = T->resource[l12];
-    uint64_t nib_v = 0;
-    if (lane == 0) nib_v = T->p1map_nib;
-    else if (lane < 3) nib_v = T->speed_nib[lane - 1];
-    else if (lane < 5) nib_v = T->control_nib[lane - 3];
-    else if (lane < 7) nib_v = T->cost_nib[lane - 5];
-    else if (lane < 9) nib_v = T->type_nib[lane - 7];
-    else if (lane == 9) nib_v = (uint64_t)(uint32_t)T->max_turns | ((uint64_t)(T->damage_nib & 0xFFFFu) << 8) | ((uint64_t)(T->fast_div ? 1u : 0u) << 24);
-    const double den_v = (&T->den_tab[0][0])[lane < 48 ? lane : 0], rcp_v = (&T->rcp_tab[0][0])[lane < 48 ? lane : 0];
+    constexpr int TV = (int)(sizeof(LdsTables) / 16);   // 104 16-byte pieces: two loads per lane
+    static_assert(TV > WG && TV <= 2 * WG, "table blob is copied in two rounds");
+    const uint4* timg = reinterpret_cast<const uint4*>(&T->lds);
+    const uint4 tv0 = timg[lane], tv1 = timg[lane + WG < TV ? lane + WG : 0];
     const uint32_t envw = S.env[e];
     uint32_t episode = S.episode[e];
     float ep_ret = S.ep_ret[(size_t)P * N + e];         // this player's running episode return: a register across the launch's turns
-    uint32_t st[3], g_in[12], n_in[6];
+    uint32_t st[3], g_in[12], n_in[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) st[j] = S.stamp[(size_t)(P * 3 + j) * N + e];
 #pragma unroll
     for (int k = 0; k < 12; ++k) g_in[k] = S.grp[(size_t)(P * 12 + k) * N + e];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {                       // player 0 lane: nodes 1..6, player 1 lane: nodes 7..11
-        const int n = P ? 7 + j : 1 + j;
-        n_in[j] = S.node[(size_t)((n <= NN ? n : NN) - 1) * N + e];
-    }
+    for (int j = 0; j < 3; ++j) n_in[j] = S.node[(size_t)(P * 3 + j) * N + e];   // player 0 lane: nodes 1..6, player 1 lane: nodes 7..11 (two per word)
     // fused scripted agents: this seat's agent object (three words) lives in registers across the launch's turns
     uint32_t ag_cycle = 0, ag_swarm = 0, ag_dfs = 0;
     const size_t ai = (size_t)P * N + e;
@@ -363,23 +365,22 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     int turn = (int)(envw & 0xFFu);
     int status = (int)((envw >> 8) & 3u);
-    if (lane < 12) { L.adj[lane] = adj_v; L.cp[lane] = cp_v; L.ts[lane] = ts_v; L.res[lane] = res_v; }
-    if (lane < 10) L.nib[lane] = nib_v;
-    if (lane < 24) L.init_grp[lane] = ig_v;
-    if (lane < 12) L.init_node[lane] = in_v;
-    if (lane < 48) { L.den[lane] = den_v; L.rcp[lane] = rcp_v; }
+    {
+        uint4* lt = reinterpret_cast<uint4*>(&L.tab);
+        lt[lane] = tv0;
+        if (lane + WG < TV) lt[lane + WG] = tv1;
+    }
     if (envlane) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) L.G[k][lane] = g_in[k];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int n = P ? 7 + j : 1 + j;
-            if (n <= NN) L.NW[n][E] = n_in[j];
+            if (n <= NN) L.NW[n][E] = (n_in[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
     const bool observe_only = io.observe_only != 0;
-    const uint32_t abl = io.ablate;                     // diagnostic only (EVG_ABLATE); 0 in production
     // stock-entropy mode: the env's MT19937 is advanced by the lane of player 0, in the reference's draw order
     MtGen mt{nullptr, 0, 0};
     const bool mt_lane = MT && valid && P == 0;
@@ -403,9 +404,9 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const bool valid = envlane && E < nvalid;
     const int e = valid ? e0 + E : e0;
     const size_t N = (size_t)S.N;
-    const uint64_t p1nib = L.nib[0];
-    const uint64_t spd_n = L.nib[1 + P], ctl_n = L.nib[3 + P], cst_n = L.nib[5 + P], typ_n = L.nib[7 + P];
-    const uint32_t misc = (uint32_t)L.nib[9];
+    const uint64_t p1nib = L.tab.nib[0];
+    const uint64_t spd_n = L.tab.nib[1 + P], ctl_n = L.tab.nib[3 + P], cst_n = L.tab.nib[5 + P], typ_n = L.tab.nib[7 + P];
+    const uint32_t misc = (uint32_t)L.tab.nib[9];
     const int max_turns = (int)(misc & 0xFFu);
     // this player's 7 order rows: read from the caller's tensor (in the prologue), or -- in the fused rollouts -- produced
     // here by the same generators as evg_random_actions / evg_scripted_actions and written out
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // of every row can be taken from the pre-order words; rows interact only through test 1 (an id already
         // commanded this turn) and, for aliased ids, through the order of the writes (the later row wins, as in
         // the reference).  That makes the 7 LDS lookups independent instead of a 7-deep dependent chain.
-        if (!(abl & 1u)) {
+        if (!ABLATED(1u)) {
             int gidv[NA], nidv[NA], rawv[NA];
             uint32_t wv[NA], dv[NA];
             bool okv[NA];
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i)
-                dv[i] = (uint32_t)((L.adj[wv[i] & G_LOC_M] >> (4 * nidv[i])) & 15u);   // test3 + distance, :245-250
+                dv[i] = (uint32_t)((L.tab.adj[wv[i] & G_LOC_M] >> (4 * nidv[i])) & 15u);   // test3 + distance, :245-250
             uint32_t used = 0;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -493,7 +494,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const bool elig = (w & G_MASK_M) != 0 && ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;
         occ |= (elig ? 1u : 0u) << (w & G_LOC_M);
     }
-    const uint32_t contested = (play && !(abl & 2u)) ? (occ & (uint32_t)xchg1((int)occ)) : 0u;
+    const uint32_t contested = (play && !ABLATED(2u)) ? (occ & (uint32_t)xchg1((int)occ)) : 0u;
     if (__any(contested != 0)) {                          // wave-uniform: skip when none of the 32 envs fights
         uint32_t key[12];
 #pragma unroll
@@ -580,7 +581,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
             }
             for (int i = lane; i < ndwords; i += WG) L.u.c.DP[i] = 0;
-            __syncthreads();
+            WAVE_SYNC();
             STAMP(4);
 
             // health row of this lane's first item: issued now, consumed in phase B, so that the HBM latency hides
@@ -619,7 +620,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             const int SL = lane | side;
                             const uint32_t fso = L.u.c.FS[node][SL ^ 1];
                             const uint32_t tot_o = fso >> 16, doff_o = fso & 0xFFFFu;
-                            const uint64_t tn_s = L.nib[7 + side];
+                            const uint64_t tn_s = L.tab.nib[7 + side];
                             int last = -1;
                             for (;;) {
                                 int best = 256, bg = -1, bcnt = 0;
@@ -649,7 +650,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const int node = (int)((sp >> 12) & 15u), cnt = __popc(sp & 0xFFFu);
                 const uint32_t fso = L.u.c.FS[node][SL ^ 1];
                 const uint32_t tot_o = fso >> 16, doff_o = fso & 0xFFFFu;
-                const uint64_t tn_s = L.nib[7 + side];
+                const uint64_t tn_s = L.tab.nib[7 + side];
                 const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
                 const uint32_t dmg = (dmg_nib >> (4 * type)) & 15u;
                 const int turn_e = (int)L.u.c.TURN[SL];
@@ -667,7 +668,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
             }
             }
-            __syncthreads();
+            WAVE_SYNC();
             STAMP(5);
 
             // Phase B (:573-644): one lane per fighting group; the uid-th alive unit of the snapshot (list-order
@@ -713,11 +714,11 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             h[8] = h[9] = h[10] = h[11] = 0.0;
                         }
                     }
-                    const uint64_t tn_s = L.nib[7 + side];
+                    const uint64_t tn_s = L.tab.nib[7 + side];
                     const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
                     const int ctrl_by = (int)((L.NW[node][SL >> 1] >> 10) & 3u) - 1;
                     const int di = (int)type * 12 + (ctrl_by == side ? node : 0);                    // :592-597 (fort bonus dead)
-                    const double denom = L.den[di], rcp = L.rcp[di];
+                    const double denom = L.tab.den[di], rcp = L.tab.rcp[di];
                     uint32_t newmask = mask;
                     if (fast_div) {
 #pragma unroll
@@ -755,7 +756,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     L.G[gid][SL] = (w & ~(G_MASK_M | G_AVG_M)) | (newmask << G_MASK_S) | (avg << G_AVG_S);
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();
         }
     }
     STAMP(6);
@@ -764,7 +765,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     uint32_t gw[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) gw[k] = envlane ? L.G[k][col] : 0u;
-    if (play && !(abl & 4u)) {
+    if (play && !ABLATED(4u)) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
             const uint32_t w = gw[k];
@@ -802,7 +803,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         my_unit_score += cnt * (int)((cst_n >> (4 * k)) & 15u);                                 // :315-317
         my_alive += cnt;
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     // ---------------- capture (server.py:708-767) and node scores (:297-310): the pair splits the nodes
     int part0 = 0, part1 = 0;          // score contributions of this lane's nodes to player 0 / player 1
@@ -816,8 +817,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             a0v[j] = L.u.A[n][col & ~1];
             a1v[j] = L.u.A[n][col | 1];
             nwv[j] = L.NW[n][E];
-            cpv[j] = L.cp[n];
-            tsv[j] = L.ts[n];
+            cpv[j] = L.tab.cp[n];
+            tsv[j] = L.tab.ts[n];
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -927,14 +928,14 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int j = 0; j < 3; ++j) st[j] = 0;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) gw[k] = L.init_grp[P * 12 + k];
+        for (int k = 0; k < 12; ++k) gw[k] = L.tab.init_grp[P * 12 + k];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int n = P ? 7 + j : 1 + j;
-            if (n <= NN) L.NW[n][E] = L.init_node[n];
+            if (n <= NN) L.NW[n][E] = L.tab.init_node[n];
         }
     }
-    __syncthreads();        // node words final; everybody is done adding to A
+    WAVE_SYNC();        // node words final; everybody is done adding to A
     STAMP(9);
 
     // ---------------- observation of this lane's player (board_state :382-455, player_state :457-501,
@@ -946,18 +947,18 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         cs_s[i] = (int)(L.NW[n][E] & 0x3FFu) - 512;                               // control sign not mirrored
         ou_s[i] = (int)(L.u.A[n][col ^ 1] >> 16);                                // opposing units listed at the node, moving ones included
     }
-    __syncthreads();        // A is dead from here on: the union becomes the output image
+    WAVE_SYNC();        // A is dead from here on: the union becomes the output image
     int16_t* orow = &L.u.O[col * OBS];
     if (!envlane) {
         // helper lane: nothing to write
     } else if (do_reset) {
 #pragma unroll
-        for (int i = 0; i < OBS; ++i) orow[i] = P ? T->reset_obs[OBS + i] : T->reset_obs[i];
+        for (int i = 0; i < OBS; ++i) orow[i] = L.tab.reset_obs[P * OBS + i];
     } else {
         orow[0] = (int16_t)turn;
 #pragma unroll
         for (int i = 1; i <= NN; ++i) {
-            const int res = L.res[P ? (int)((p1nib >> (4 * i)) & 15u) : i];
+            const int res = L.tab.res[P ? (int)((p1nib >> (4 * i)) & 15u) : i];
             int16_t* o = orow + 1 + 4 * (i - 1);
             o[0] = (res & EVG_RES_DEFENSE) ? 1 : 0;                                // :442
             o[1] = (res & EVG_RES_OBSERVE) ? 1 : 0;                                // :443
@@ -980,15 +981,16 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---------------- store state (coalesced)
     // (multi-turn form: the state lives on chip between turns and goes back to HBM after the launch's last turn)
-    if (valid && !observe_only && (MULTI ? iter == nturns - 1 : (play || do_reset)) && !(abl & 32u)) {
+    if (valid && !observe_only && (MULTI ? iter == nturns - 1 : (play || do_reset)) && !ABLATED(32u)) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) S.grp[(size_t)(P * 12 + k) * N + e] = gw[k];
 #pragma unroll
         for (int j = 0; j < 3; ++j) S.stamp[(size_t)(P * 3 + j) * N + e] = st[j];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int n = P ? 7 + j : 1 + j;
-            if (n <= NN) S.node[(size_t)(n - 1) * N + e] = (uint16_t)L.NW[n][E];
+        for (int j = 0; j < 3; ++j) {
+            const int n = (P ? 7 : 1) + 2 * j;          // word P*3+j holds nodes n (low half) and n+1 (high half; ID 12 does not exist)
+            const uint32_t hi = n + 1 <= NN ? (L.NW[(n + 1) % 12][E] & 0xFFFFu) : 0u;
+            S.node[(size_t)(P * 3 + j) * N + e] = (L.NW[n][E] & 0xFFFFu) | (hi << 16);
         }
         if (P == 0) {
             S.env[e] = (uint32_t)turn | ((uint32_t)status << 8);
@@ -1000,12 +1002,12 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int k = 0; k < 12; ++k) L.G[k][lane] = gw[k];
     }
-    __syncthreads();        // output image complete; combat's health stores drained
+    WAVE_SYNC();             // output image complete
     STAMP(11);
 
     // ---------------- observation write-out: the wave's 32 x 210 values are contiguous in the output; every lane
     // converts 16 bytes' worth per iteration (conflict-free LDS reads, fully coalesced 1 KiB stores per wave)
-    if (io.obs && !(abl & 16u)) {
+    if (io.obs && !ABLATED(16u)) {
         constexpr int EP = 16 / (int)sizeof(OT);          // elements per 16-byte vector
         constexpr int NVEC = LPW * OBS / EP;
         const int limit = nvalid * OBS2;
@@ -1069,7 +1071,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int i = lane; i < NU; i += WG) dst[i] = make_double2(100.0, 100.0);
     }
     STAMP(13);
-    if (MULTI) __syncthreads();                         // this turn's health/output stores have left the wave before the next turn reads
+    if (MULTI) WAVE_SYNC();                             // next turn's LDS traffic stays behind this turn's (global accesses of one wave are issued in order)
     }   // turns
 }
 
@@ -1093,7 +1095,7 @@ __global__ void __launch_bounds__(WG) evg_reset_kernel(DevState S, const uint8_t
 #pragma unroll
         for (int j = 0; j < 6; ++j) S.stamp[(size_t)j * N + e] = 0;
 #pragma unroll
-        for (int n = 1; n <= NN; ++n) S.node[(size_t)(n - 1) * N + e] = (uint16_t)T->init_node[n];
+        for (int j = 0; j < 6; ++j) S.node[(size_t)j * N + e] = (T->init_node[2 * j + 1] & 0xFFFFu) | (2 * j + 2 <= NN ? (T->init_node[2 * j + 2] & 0xFFFFu) << 16 : 0u);
         S.env[e] = 0;
         S.episode[e] += 1u;                 // 0xFFFFFFFF at create -> episode 0 on the first reset
         S.ep_ret[e] = 0.f;
@@ -1184,7 +1186,7 @@ __global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* fog, 
     uint32_t seen_by_tower = 0;
 #pragma unroll
     for (int n = 1; n <= NN; ++n) {
-        const uint32_t nw = S.node[(size_t)(n - 1) * N + e];
+        const uint32_t nw = (S.node[(size_t)((n - 1) >> 1) * N + e] >> (16 * ((n - 1) & 1))) & 0xFFFFu;
         const int cb = (int)((nw >> 10) & 3u) - 1, cs = (int)(nw & 0x3FFu) - 512;
         const bool mine = cb == p, obs = (T->resource[n] & EVG_RES_OBSERVE) != 0;
         ctrl |= (mine ? 1u : 0u) << n;
@@ -1320,7 +1322,9 @@ int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream
         }
         return (int)hipGetLastError();
     }
+#ifdef EVG_DIAG
     if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
+#endif
     return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);
 }
 

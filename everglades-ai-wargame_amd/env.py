@@ -169,4 +169,8 @@ class EvergladesEnv(object):
         return None
 
     def close(self):
-        pass
+        """everglades_env.py:118-122 closes the viewer; here the game's device state is released."""
+        if self._vec is not None:
+            self._vec.close()
+            self._vec = None
+            self._cfg_key = None

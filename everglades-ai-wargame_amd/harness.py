@@ -54,13 +54,14 @@ def evaluate(player0, player1, episodes, num_envs=4096, seed=0, device=None, alp
         env = EvergladesVecEnv(num_envs, device=device, seed=seed, auto_reset=False)
     assert env.num_envs == num_envs and not env.auto_reset, "evaluate() needs a handle without auto-reset"
     both_native = _is_device_policy(player0) and _is_device_policy(player1)
+    max_turns = int(env.tables.max_turns)          # the handle's own turn limit (150 for the reference's tables, server.py:321)
     winners, lengths = [], []
     for _ in range(rounds):
         obs = env.reset()
         if both_native:
-            env.rollout_policies(env.num_turns, player0, player1, fused=True, turns_per_launch=turns_per_launch)   # finished envs stay frozen
+            env.rollout_policies(max_turns, player0, player1, fused=True, turns_per_launch=turns_per_launch)   # finished envs stay frozen
         else:
-            for _t in range(env.num_turns):
+            for _t in range(max_turns):
                 acts = env._actions
                 for seat, pl in ((0, player0), (1, player1)):
                     if _is_device_policy(pl):

@@ -30,12 +30,14 @@ class EvergladesVecEnv(object):
     obs_len = _lib.OBS_LEN
 
     def __init__(self, num_envs, device=None, seed=0, env_id_base=0, obs_dtype="float32", auto_reset=True, tables=None,
-                 map_file=None, unit_file=None, config_dir=None, rng_mode="philox"):
+                 map_file=None, unit_file=None, config_dir=None, rng_mode="philox", library=None, diag=None):
         """rng_mode "philox" (default, the fast keyed draws of DESIGN.md section 4) or "mt19937": every env owns numpy's legacy
         generator seeded like np.random.seed((seed + env_id_base + e) & 0xFFFFFFFF) and consumes it in the reference's
-        order, so a game replays the UNMODIFIED reference process bit for bit (validation mode, sequential draws)."""
+        order, so a game replays the UNMODIFIED reference process bit for bit (validation mode, sequential draws).
+        library / diag: diagnostics only -- path of a diagnostic build of the library (default: the product libevg.so) and, for
+        libevg_diag.so, dict(ablate=bits, lanes=32|64, force_ieee_div=bool) passed to its evg_diag_configure."""
         torch = _torch()
-        self.L = _lib.load()
+        self.L = _lib.load(library)
         if not torch.cuda.is_available():
             raise _lib.EvgError("EvergladesVecEnv needs a HIP device (MI355X); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -65,8 +67,12 @@ class EvergladesVecEnv(object):
         cfg.rng_mode = modes[rng_mode]
         cfg.tables = tables
         h = C.c_void_p()
-        _lib.check(self.L.evg_create(C.byref(cfg), C.byref(h)))
+        self._check(self.L.evg_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        if diag:
+            if not hasattr(self.L, "evg_diag_configure"):
+                raise _lib.EvgError("diag options need a diagnostic library (library=_lib.DIAG_LIB_PATH); the product library has none")
+            self._check(self.L.evg_diag_configure(h, int(diag.get("ablate", 0)), int(diag.get("lanes", 64)), int(bool(diag.get("force_ieee_div", False)))))
         N = self.num_envs
         with torch.cuda.device(self.device):
             self.obs = torch.zeros((N, 2, _lib.OBS_LEN), dtype=self.obs_dtype, device=self.device)
@@ -84,6 +90,10 @@ class EvergladesVecEnv(object):
         self._int32 = torch.int32
 
     # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc:
+            _lib.check(rc, self.L)
+
     def _stream(self):
         if self._raw_stream is not None:        # raw hipStream_t of torch's current stream without building a Stream object
             return C.c_void_p(self._raw_stream(self.device.index))
@@ -92,6 +102,16 @@ class EvergladesVecEnv(object):
     @staticmethod
     def _ptr(t):
         return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _user(self, t, shape, dtype, name):
+        """A caller-supplied tensor reaches the kernels as a raw pointer: it must be exactly what the kernel assumes."""
+        torch = _torch()
+        if not isinstance(t, torch.Tensor):
+            raise ValueError("%s must be a torch tensor on %s" % (name, self.device))
+        if t.device != self.device or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s, got %s %s on %s%s" % (
+                name, dtype, tuple(shape), self.device, t.dtype, tuple(t.shape), t.device, "" if t.is_contiguous() else " (not contiguous)"))
+        return t
 
     def close(self):
         if getattr(self, "_h", None):
@@ -114,7 +134,7 @@ class EvergladesVecEnv(object):
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
             assert m.shape == (self.num_envs,)
-        _lib.check(self.L.evg_reset(self._h, self._ptr(m), self._ptr(self.obs), self._stream()))
+        self._check(self.L.evg_reset(self._h, self._ptr(m), self._ptr(self.obs), self._stream()))
         return self.obs
 
     def _as_actions(self, actions):
@@ -141,11 +161,11 @@ class EvergladesVecEnv(object):
         rc = self.L.evg_step(self._h, C.c_void_p(a.data_ptr()), p["obs"], p["reward"], p["done"], p["winner"], p["scores"], p["status"],
                              self._stream())
         if rc:
-            _lib.check(rc)
+            self._check(rc)
         return self.obs, self.reward, self.done, self._info
 
     def observe(self):
-        _lib.check(self.L.evg_observe(self._h, self._ptr(self.obs), self._stream()))
+        self._check(self.L.evg_observe(self._h, self._ptr(self.obs), self._stream()))
         return self.obs
 
     def fog_of_war(self, out=None):
@@ -155,7 +175,8 @@ class EvergladesVecEnv(object):
             if getattr(self, "_fog", None) is None:
                 self._fog = torch.zeros((self.num_envs, 2, _lib.NUM_NODES), dtype=torch.uint8, device=self.device)
             out = self._fog
-        _lib.check(self.L.evg_fog_of_war(self._h, self._ptr(out), None, self._stream()))
+        self._user(out, (self.num_envs, 2, _lib.NUM_NODES), torch.uint8, "out")
+        self._check(self.L.evg_fog_of_war(self._h, self._ptr(out), None, self._stream()))
         return out
 
     def knowledge(self, out=None):
@@ -165,7 +186,8 @@ class EvergladesVecEnv(object):
             if getattr(self, "_know", None) is None:
                 self._know = torch.zeros((self.num_envs, 2, _lib.NUM_NODES), dtype=torch.uint8, device=self.device)
             out = self._know
-        _lib.check(self.L.evg_fog_of_war(self._h, None, self._ptr(out), self._stream()))
+        self._user(out, (self.num_envs, 2, _lib.NUM_NODES), torch.uint8, "out")
+        self._check(self.L.evg_fog_of_war(self._h, None, self._ptr(out), self._stream()))
         return out
 
     def sightings(self, out=None):
@@ -176,7 +198,8 @@ class EvergladesVecEnv(object):
             if getattr(self, "_sight", None) is None:
                 self._sight = torch.zeros((self.num_envs, 2, _lib.NUM_GROUPS, 4), dtype=torch.int8, device=self.device)
             out = self._sight
-        _lib.check(self.L.evg_sightings(self._h, self._ptr(out), self._stream()))
+        self._user(out, (self.num_envs, 2, _lib.NUM_GROUPS, 4), torch.int8, "out")
+        self._check(self.L.evg_sightings(self._h, self._ptr(out), self._stream()))
         return out
 
     def smart_state(self, player, obs=None, out=None):
@@ -186,7 +209,9 @@ class EvergladesVecEnv(object):
         obs = self.obs if obs is None else obs
         if out is None:
             out = torch.empty((self.num_envs, _lib.NUM_GROUPS, 59), dtype=torch.float32, device=self.device)
-        _lib.check(self.L.evg_smart_state(self._h, int(player), self._ptr(obs), self._ptr(out), self._stream()))
+        self._user(obs, (self.num_envs, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
+        self._user(out, (self.num_envs, _lib.NUM_GROUPS, 59), torch.float32, "out")
+        self._check(self.L.evg_smart_state(self._h, int(player), self._ptr(obs), self._ptr(out), self._stream()))
         return out
 
     @staticmethod
@@ -198,8 +223,8 @@ class EvergladesVecEnv(object):
 
     def random_actions(self, out=None):
         """On-device equivalent of agents/State_Machine/random_actions.py for both players of every env."""
-        out = self._actions if out is None else out
-        _lib.check(self.L.evg_random_actions(self._h, self._ptr(out), self._stream()))
+        out = self._actions if out is None else self._user(out, self._act_shape, self._int32, "out")
+        self._check(self.L.evg_random_actions(self._h, self._ptr(out), self._stream()))
         return out
 
     POLICIES = dict({n: i for i, n in enumerate(_lib.POLICY_NAMES)}, **_lib.POLICY_ALIASES)
@@ -213,12 +238,13 @@ class EvergladesVecEnv(object):
         obs = self.obs if obs is None else obs
         out = self._actions if out is None else out
         pid = self.POLICIES[policy] if isinstance(policy, str) else int(policy)
-        assert obs.dtype == self.obs_dtype and obs.is_contiguous() and tuple(obs.shape) == (self.num_envs, 2, _lib.OBS_LEN)
-        _lib.check(self.L.evg_scripted_actions(self._h, pid, int(player), self._ptr(obs), self._ptr(out), self._stream()))
+        self._user(obs, (self.num_envs, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
+        self._user(out, self._act_shape, self._int32, "out")
+        self._check(self.L.evg_scripted_actions(self._h, pid, int(player), self._ptr(obs), self._ptr(out), self._stream()))
         return out
 
     def scripted_reset(self):
-        _lib.check(self.L.evg_scripted_reset(self._h, self._stream()))
+        self._check(self.L.evg_scripted_reset(self._h, self._stream()))
 
     def rollout_random(self, steps, time_kernel=False, fused=True, turns_per_launch=1):
         """`steps` turns of random-vs-random play driven from native code (evg_rollout_random): per turn the
@@ -227,7 +253,7 @@ class EvergladesVecEnv(object):
         consecutive turns per wavefront, outputs still written every turn).  Returns the outputs of
         the last turn like step(); with time_kernel=True also the average step-kernel time in ms (synchronises)."""
         ms = C.c_float(0.0)
-        _lib.check(self.L.evg_rollout_random(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
+        self._check(self.L.evg_rollout_random(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
                                              self._ptr(self.done), self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status),
                                              C.byref(ms) if time_kernel else None, self._stream()))
         out = (self.obs, self.reward, self.done, dict(winner=self.winner, scores=self.scores, status=self.status))
@@ -241,7 +267,7 @@ class EvergladesVecEnv(object):
         ms = C.c_float(0.0)
         p0 = self.POLICIES[policy0] if isinstance(policy0, str) else int(policy0)
         p1 = self.POLICIES[policy1] if isinstance(policy1, str) else int(policy1)
-        _lib.check(self.L.evg_rollout_policies(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p0, p1, self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
+        self._check(self.L.evg_rollout_policies(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p0, p1, self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
                                                self._ptr(self.done), self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status),
                                                C.byref(ms) if time_kernel else None, self._stream()))
         out = (self.obs, self.reward, self.done, self._info)
@@ -253,7 +279,7 @@ class EvergladesVecEnv(object):
         s = dict(groups=np.zeros((N, 2, 12, 8), np.int32), nodes=np.zeros((N, 11, 2), np.int32),
                  health=np.zeros((N, 2, 100), np.float64), env=np.zeros((N, 4), np.int32))
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        _lib.check(self.L.evg_get_state(self._h, p(s["groups"]), p(s["nodes"]), p(s["health"]), p(s["env"])))
+        self._check(self.L.evg_get_state(self._h, p(s["groups"]), p(s["nodes"]), p(s["health"]), p(s["env"])))
         return s
 
     def set_state(self, groups, nodes, health, env):
@@ -265,7 +291,7 @@ class EvergladesVecEnv(object):
         if g.shape != (N, 2, 12, 8) or n.shape != (N, 11, 2) or h.shape != (N, 2, 100) or e.shape != (N, 4):
             raise ValueError("set_state: wrong array shapes")
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        _lib.check(self.L.evg_set_state(self._h, p(g), p(n), p(h), p(e)))
+        self._check(self.L.evg_set_state(self._h, p(g), p(n), p(h), p(e)))
 
     def seed_stock_entropy(self, seeds=None):
         """rng_mode="mt19937": np.random.seed(seeds[e]) for every env (None: the create-time rule seed + env_id_base + e)."""
@@ -274,32 +300,33 @@ class EvergladesVecEnv(object):
             a = np.ascontiguousarray(np.asarray(seeds, np.uint64) & 0xFFFFFFFF, np.uint32)
             if a.shape != (self.num_envs,):
                 raise ValueError("seeds must have one entry per env")
-        _lib.check(self.L.evg_seed_stock_entropy(self._h, None if a is None else a.ctypes.data_as(C.c_void_p), self._stream()))
+        self._check(self.L.evg_seed_stock_entropy(self._h, None if a is None else a.ctypes.data_as(C.c_void_p), self._stream()))
 
     def get_stock_entropy(self):
         """uint32 [N, 625]: the 624 key words and the position of every env's MT19937 (np.random.get_state()[1:3])."""
         a = np.zeros((self.num_envs, 625), np.uint32)
-        _lib.check(self.L.evg_get_stock_entropy(self._h, a.ctypes.data_as(C.c_void_p)))
+        self._check(self.L.evg_get_stock_entropy(self._h, a.ctypes.data_as(C.c_void_p)))
         return a
 
     def set_stock_entropy(self, state):
         a = np.ascontiguousarray(state, np.uint32)
         if a.shape != (self.num_envs, 625):
             raise ValueError("state must be uint32 [N, 625]")
-        _lib.check(self.L.evg_set_stock_entropy(self._h, a.ctypes.data_as(C.c_void_p)))
+        self._check(self.L.evg_set_stock_entropy(self._h, a.ctypes.data_as(C.c_void_p)))
 
     def episode_stats(self):
         N = self.num_envs
         r, ln, w, tot = np.zeros((N, 2), np.float32), np.zeros(N, np.int32), np.zeros(N, np.int8), np.zeros(4, np.int64)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        _lib.check(self.L.evg_episode_stats(self._h, p(r), p(ln), p(w), p(tot)))
+        self._check(self.L.evg_episode_stats(self._h, p(r), p(ln), p(w), p(tot)))
         return dict(returns=r, length=ln, winner=w, totals=tot)
 
     def episode_stats_device(self):
-        """Zero-copy torch views of the per-env results of the last finished episode (for the multi-GPU gather)."""
+        """Zero-copy torch views of the per-env results of the last finished episode (for the multi-GPU gather).  They alias
+        memory owned by the handle: they are valid until close() and must not be used afterwards."""
         torch = _torch()
         pr, pl, pw = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _lib.check(self.L.evg_episode_stats_device(self._h, C.byref(pr), C.byref(pl), C.byref(pw)))
+        self._check(self.L.evg_episode_stats_device(self._h, C.byref(pr), C.byref(pl), C.byref(pw)))
         N = self.num_envs
 
         def view(ptr, shape, dtype, itemsize):

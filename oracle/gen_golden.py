@@ -9,7 +9,8 @@ reference itself is written: the fixtures hold action streams, observations, rew
 scores, status and state snapshots (numbers), which is what the parity tests replay
 through the C oracle and through the HIP path.
 
-    python oracle/gen_golden.py            # regenerate everything (about 2 minutes)
+    python oracle/gen_golden.py            # regenerate everything but the 10 000-match sample (about 2 minutes)
+    EVG_GOLDEN_ONLY=matches python oracle/gen_golden.py    # tests/golden/matches_10k.npz (about 10 minutes on 6 cores)
 
 Loader recipe: SURVEY.md Appendix B (np.int alias; a stub `gym` package so the real
 gym_everglades/envs/everglades_env.py imports unmodified).
@@ -640,6 +641,78 @@ def gen_smart_state_fixture():
 
 
 # ----------------------------------------------------------------------------------------------
+# north-star acceptance sample: 10 000 seeded random-vs-random matches played by the reference
+# ----------------------------------------------------------------------------------------------
+MATCH_SEED, MATCH_COUNT = 20261004, 10000
+_match_runner = None
+
+
+def _match_worker(span):
+    """Plays games [lo, hi) on this process's own copy of the imported reference: the harness loop of
+    demo/random_demo.py:90-113 / evaluate.py:127-160 with both seats = the random_actions generator contract, combat
+    entropy injected as everywhere else.  Only outcomes are kept (no per-turn state)."""
+    global _match_runner
+    if _match_runner is None:
+        _match_runner = Runner()
+    R = _match_runner
+    lo, hi = span
+    n = hi - lo
+    out = dict(length=np.zeros(n, np.int16), scores=np.zeros((n, 2), np.int32), status=np.zeros(n, np.uint8),
+               reward=np.zeros((n, 2), np.float64), returns=np.zeros((n, 2), np.float64), winner=np.zeros(n, np.int8),
+               obs_final_sum=np.zeros((n, 2), np.int32), alive_final=np.zeros((n, 2), np.int16), draws=np.zeros(n, np.int32))
+    for i in range(n):
+        env_id = lo + i
+        obs = R.reset(MATCH_SEED, env_id, 0)
+        game = R.env.game
+        box = {}
+        orig = game.game_turn
+
+        def wrapped(actions, _o=orig, _b=box):
+            s, st = _o(actions)
+            _b["scores"], _b["status"] = (int(s[0]), int(s[1])), int(st)
+            return s, st
+
+        game.game_turn = wrapped
+        d0 = R.proxy.draws
+        done, t, ret = 0, 0, [0.0, 0.0]
+        while not done:
+            acts = {p: np.array(rng_spec.random_action_rows(MATCH_SEED, env_id, 0, int(obs[p][0]), p), dtype=np.float64) for p in (0, 1)}
+            obs, reward, done, info = R.env.step(acts)
+            ret[0] += float(reward[0]); ret[1] += float(reward[1])
+            t += 1
+        out["length"][i], out["scores"][i], out["status"][i] = t, box["scores"], box["status"]
+        out["reward"][i] = [float(reward[0]), float(reward[1])]
+        out["returns"][i] = ret
+        out["winner"][i] = 0 if reward[0] > reward[1] else (2 if reward[0] == reward[1] else 1)      # evaluate.py:155-160
+        out["obs_final_sum"][i] = [int(np.sum(obs[0])), int(np.sum(obs[1]))]
+        out["alive_final"][i] = [int(np.sum(obs[p][49::5])) for p in (0, 1)]
+        out["draws"][i] = R.proxy.draws - d0
+    return lo, out
+
+
+def gen_matches_fixture(procs=6, chunk=50):
+    """tests/golden/matches_10k.npz: BASELINE north_star "bit-identical win counts vs the CPU reference over 10 000
+    seeded matches" -- env ids 0..9999 of seed MATCH_SEED, episode 0, one game each, played by the imported reference."""
+    import multiprocessing as mp
+    t0 = time.time()
+    spans = [(lo, min(lo + chunk, MATCH_COUNT)) for lo in range(0, MATCH_COUNT, chunk)]
+    parts = {}
+    with mp.get_context("fork").Pool(procs) as pool:
+        for k, (lo, o) in enumerate(pool.imap_unordered(_match_worker, spans)):
+            parts[lo] = o
+            if k % 10 == 9:
+                print("matches: %d / %d games, %.0fs" % ((k + 1) * chunk, MATCH_COUNT, time.time() - t0), flush=True)
+    keys = list(parts[0].keys())
+    d = {k: np.concatenate([parts[lo][k] for lo in sorted(parts)]) for k in keys}
+    d["seed"] = np.array([MATCH_SEED], np.uint64)
+    w = d["winner"]
+    d["wins_p0_p1_tie"] = np.array([int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum())], np.int32)
+    np.savez_compressed(os.path.join(OUT, "matches_10k.npz"), **d)
+    print("matches_10k: wins p0/p1/tie", d["wins_p0_p1_tie"].tolist(), "status histogram", np.bincount(d["status"], minlength=4).tolist(),
+          "mean length %.2f" % d["length"].mean(), "%.0fs" % (time.time() - t0), flush=True)
+
+
+# ----------------------------------------------------------------------------------------------
 def kat_script():
     """deterministic no-combat trajectory."""
     z = np.zeros((7, 2))
@@ -674,6 +747,9 @@ def edit_annihilation(game):
 def main():
     os.makedirs(OUT, exist_ok=True)
     t0 = time.time()
+    if os.environ.get("EVG_GOLDEN_ONLY") == "matches":       # workers load their own copy of the reference
+        gen_matches_fixture(procs=int(os.environ.get("EVG_GOLDEN_PROCS", "6")))
+        return
     R = Runner()
     stats = {}
     if os.environ.get("EVG_GOLDEN_ONLY") == "agents":

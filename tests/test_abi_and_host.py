@@ -172,3 +172,47 @@ def test_render_is_a_warning_noop(evg):
         assert env.render() is None and env.render(mode="human") is None
     assert len(w) == 1 and "not part of the accelerated path" in str(w[0].message)
     env.close()
+
+
+def test_product_library_has_no_diagnostic_hooks(evg):
+    """The product library reads no environment variable and exports no diagnostic entry point; the kernel's ablation
+    branches, the 16-envs-per-wave variant and the forced-division switch exist only in libevg_diag.so (make diag)."""
+    import subprocess
+    lib_path = evg._lib.LIB_PATH
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", lib_path], text=True)
+    assert "getenv" not in undefined, "libevg.so must not read the environment"
+    defined = subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True)
+    assert "evg_diag_configure" not in defined and "evg_debug_read_stamps" not in defined
+    assert "evg_step_kernelIfLi32" not in defined                  # no 16-envs-per-wave instantiation of the step kernel
+    src = open(os.path.join(ROOT, "everglades-ai-wargame_amd", "_lib.py")).read() + open(os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc", "evg_abi.hip")).read()
+    assert "getenv" not in src and "os.environ" not in src
+    if os.path.exists(evg._lib.DIAG_LIB_PATH):
+        assert "evg_diag_configure" in subprocess.check_output(["nm", "-D", "--defined-only", evg._lib.DIAG_LIB_PATH], text=True)
+
+
+def test_create_rejects_bad_arguments_before_touching_a_device(evg):
+    """Argument validation of evg_create that comes before device discovery: wrong struct size / ABI version, no envs, global env
+    ids beyond the 32-bit key space of the random streams."""
+    lib = evg.load_library()
+
+    def create(**kw):
+        cfg = evg._lib.EvgConfig()
+        cfg.struct_size, cfg.abi_version, cfg.num_envs, cfg.device_id = C.sizeof(evg._lib.EvgConfig), evg._lib.ABI_VERSION, 4, 0
+        cfg.tables = evg.default_tables()
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.evg_create(C.byref(cfg), C.byref(h))
+        assert (rc == 0) == bool(h.value)
+        if h.value:
+            lib.evg_destroy(h)
+        return rc, lib.evg_last_error().decode()
+
+    assert create(struct_size=8)[0] == -1 and "mismatch" in create(struct_size=8)[1]
+    assert create(abi_version=evg._lib.ABI_VERSION + 1)[0] == -1
+    assert create(num_envs=0)[0] == -1
+    rc, msg = create(env_id_base=2 ** 32 - 2)
+    assert rc == -1 and "2^32" in msg
+    assert create(env_id_base=2 ** 40)[0] == -1
+    assert create(env_id_base=2 ** 32 - 4)[0] in (0, -2)          # fits exactly: accepted (or no device here)
+    assert lib.evg_create(None, None) == -1

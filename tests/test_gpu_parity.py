@@ -443,13 +443,12 @@ def test_persistent_multi_turn_rollout_equals_stepwise(evg, oracle_mod, tpl):
     a.close()
 
 
-def test_16_envs_per_wave_variant_matches_oracle(evg, oracle_mod, monkeypatch):
-    """EVG_LANES=32 selects the step-kernel variant with 16 envs per wavefront (32 helper lanes join the balanced
-    phases); slower on MI355X but kept as an option -- it must give the same results, single- and multi-turn."""
-    monkeypatch.setenv("EVG_LANES", "32")
+def test_16_envs_per_wave_variant_matches_oracle(evg, oracle_mod):
+    """The step-kernel variant with 16 envs per wavefront (32 helper lanes join the balanced phases) is slower on MI355X and
+    lives only in the diagnostic library (libevg_diag.so, evg_diag_configure): it must give the same results, single- and
+    multi-turn."""
     N, seed, steps = 333, 31, 170
-    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
-    monkeypatch.delenv("EVG_LANES")
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=32))
     ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
     env.reset(); ora.reset()
     for t in range(40):
@@ -742,17 +741,17 @@ def _custom_tables(evg, oracle_mod):
 
 
 @pytest.mark.parametrize("force_ieee_div", [False, True])
-def test_custom_tables_vs_oracle(evg, oracle_mod, monkeypatch, force_ieee_div):
+def test_custom_tables_vs_oracle(evg, oracle_mod, force_ieee_div):
     """Every runtime table changed (map distances, control points, non-dyadic defenses, resources, unit stats, turn limit):
     brawl and random play with auto-reset stay bit-equal to the oracle built from the same tables -- once with the exact
-    table-reciprocal quotient (validated per table set at evg_create) and once with the kernel's true-division branch
-    forced (EVG_FORCE_IEEE_DIV, a test hook)."""
+    table-reciprocal quotient (validated per table set at evg_create; the product library) and once with the kernel's
+    true-division branch, which a table set that fails that validation would run: no realistic table does (a search over
+    2e7 denominators found none), so the branch is forced through the diagnostic library's evg_diag_configure."""
     from gen_policies import policy_actions
-    if force_ieee_div:
-        monkeypatch.setenv("EVG_FORCE_IEEE_DIV", "1")
     t, ot = _custom_tables(evg, oracle_mod)
     N, seed = 224, 31
-    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, tables=t)
+    extra = dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(force_ieee_div=True)) if force_ieee_div else {}
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, tables=t, **extra)
     ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True, tables=ot)
     obs = _np(env.reset()).astype(np.float64)
     assert np.array_equal(obs, ora.reset())

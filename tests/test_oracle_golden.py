@@ -217,3 +217,55 @@ def test_config1_shared_numpy_stream(oracle_mod):
         assert np.array_equal(fin[1], d["final_key"]) and fin[2] == int(d["final_pos"][0])
     finally:
         np.random.set_state(saved)
+
+
+def play_matches(make_env_step, d):
+    """Shared by the CPU and the GPU test of tests/golden/matches_10k.npz: plays the 10 000 games (env ids 0..9999 of the
+    fixture's seed, episode 0, random vs random from the action-generator contract, no auto-reset) and returns what the
+    fixture holds per game.  make_env_step() -> (step(t) -> obs_sums [N,2], scores [N,2], status [N], reward [N,2], done [N])."""
+    n = len(d["length"])
+    step = make_env_step(n, int(d["seed"][0]))
+    length = np.zeros(n, np.int16)
+    scores, status = np.zeros((n, 2), np.int32), np.zeros(n, np.uint8)
+    reward, returns = np.zeros((n, 2), np.float64), np.zeros((n, 2), np.float64)
+    osum, alive = np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int16)
+    live = np.ones(n, bool)
+    for t in range(150):
+        obs_sum, alive_now, sc, stt, rew, done = step(t)
+        returns[live] += rew[live]
+        ending = live & (done != 0)
+        length[ending] = t + 1
+        scores[ending], status[ending], reward[ending] = sc[ending], stt[ending], rew[ending]
+        osum[ending], alive[ending] = obs_sum[ending], alive_now[ending]
+        live &= ~ending
+    assert not live.any()
+    winner = np.where(reward[:, 0] > reward[:, 1], 0, np.where(reward[:, 0] == reward[:, 1], 2, 1)).astype(np.int8)   # evaluate.py:155-160
+    return dict(length=length, scores=scores, status=status, reward=reward, returns=returns, winner=winner, obs_final_sum=osum, alive_final=alive)
+
+
+def check_matches(got, d):
+    for k in ("length", "scores", "status", "winner", "obs_final_sum", "alive_final"):
+        assert np.array_equal(got[k], d[k]), k
+    assert np.allclose(got["reward"], d["reward"], rtol=0, atol=1e-6)
+    assert np.allclose(got["returns"], d["returns"], rtol=0, atol=2e-4)      # sum of <= 150 rewards; float32 rewards on the device
+    wins = [int((got["winner"] == k).sum()) for k in (0, 1, 2)]
+    assert wins == d["wins_p0_p1_tie"].tolist(), ("win counts", wins, d["wins_p0_p1_tie"].tolist())
+
+
+def test_ten_thousand_reference_matches(oracle_mod):
+    """BASELINE north_star: "bit-identical win counts vs the CPU reference over 10 000 seeded matches".  The fixture holds the
+    outcome of 10 000 random-vs-random games played by the imported reference (oracle/gen_golden.py, EVG_GOLDEN_ONLY=matches):
+    the oracle reproduces every game -- length, final scores, status, terminal rewards, winner, the checksum of both final
+    observations, units alive -- and hence the win/tie counts."""
+    d = load_golden("matches_10k.npz")
+    assert len(d["length"]) == 10000 and d["wins_p0_p1_tie"].sum() == 10000
+
+    def make(n, seed):
+        o = oracle_mod.Oracle(n, seed=seed, env_id_base=0)
+        o.reset()
+
+        def step(t):
+            obs, rew, done, info = o.step(o.random_actions())
+            return obs.sum(axis=2).astype(np.int32), obs[:, :, 49::5].sum(axis=2).astype(np.int16), info["scores"], info["status"], rew, done
+        return step
+    check_matches(play_matches(make, d), d)

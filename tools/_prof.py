@@ -1,0 +1,46 @@
+"""Shared by tools/pmc_summary.py and tools/sq_summary.py: reading rocprofv3 CSV output of the bench command and
+selecting the step-kernel dispatches of the TIMED window (the last 150 turns of the run; the pre-roll, settle and
+warm-up launches before them are not part of any reported figure)."""
+import csv, glob, hashlib, json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FORMS = {"persistent": ("true, false>", 150, 1), "perturn": ("false, false>", 1, 150)}   # kernel-name tail, turns per launch, launches in the timed window
+FORM_KEY = {"persistent": "persistent", "perturn": "one_launch_per_turn"}
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "evg.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def step_kernel(name, form, dtype="float"):
+    return "evg_step_kernel<%s, 64, %s" % (dtype, FORMS[form][0]) in name
+
+
+def counter_rows(directory, form):
+    """{counter: [value per dispatch, in dispatch order]} and the matching [duration ns] of the step kernel of `form`."""
+    f = glob.glob(os.path.join(directory, "*", "*_counter_collection.csv"))[0]
+    per = {}
+    meta = {}
+    for r in csv.DictReader(open(f)):
+        if not step_kernel(r["Kernel_Name"], form):
+            continue
+        did = int(r["Dispatch_Id"])
+        per.setdefault(did, {})[r["Counter_Name"]] = float(r["Counter_Value"])
+        meta[did] = dict(ns=int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), grid=int(r["Grid_Size"]), vgpr=int(r["VGPR_Count"]), agpr=int(r["Accum_VGPR_Count"]),
+                         sgpr=int(r["SGPR_Count"]), lds=int(r["LDS_Block_Size"]), scratch=int(r["Scratch_Size"]), name=r["Kernel_Name"])
+    ids = sorted(per)
+    return [per[i] for i in ids], [meta[i] for i in ids]
+
+
+def timed_window(rows, form):
+    return rows[-FORMS[form][2]:]
+
+
+def trace_durations(directory, form):
+    """durations (ns) of the step kernel's dispatches, in dispatch order, from a --kernel-trace CSV"""
+    f = glob.glob(os.path.join(directory, "*", "*_kernel_trace.csv"))[0]
+    rows = [(int(r["Dispatch_Id"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if step_kernel(r["Kernel_Name"], form)]
+    return [d for _, d in sorted(rows)]

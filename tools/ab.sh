@@ -1,14 +1,15 @@
 #!/bin/bash
-# A/B on ONE box: bench the committed baseline build (libevg_base.so) and the working build (libevg.so) alternately.
+# A/B on ONE box: bench a baseline build (libevg_base.so, a copy of an earlier libevg.so) and the working build (libevg.so)
+# alternately, through bench.py's diagnostic --library switch.
 # usage (inside gpurun): bash tools/ab.sh [extra bench.py args]   -> gpurun_out/ab.txt
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 : > gpurun_out/ab.txt
 for rep in 1 2 3; do
   for lib in libevg_base.so libevg.so; do
-    EVG_LIB_PATH=$PWD/everglades-ai-wargame_amd/$lib timeout -k 10 200 python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
+    timeout -k 10 200 python bench.py --no-cpu-baseline --library $PWD/everglades-ai-wargame_amd/$lib "$@" 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); o=d['config']['one_launch_per_turn'] or {}
+d=json.loads(sys.stdin.read()); o=d['config'].get('one_launch_per_turn') or {}
 print('$lib', 'persistent %.3f G  kernel %.2f us | per-turn %.3f G  kernel %.2f us' % (d['value']/1e9, d['roofline']['kernel_ms']*1e3, o.get('env_steps_per_s',0)/1e9, o.get('kernel_ms',0)*1e3))" >> gpurun_out/ab.txt || exit 1
   done
 done

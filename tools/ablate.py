@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: price the phases of the step kernel by skipping them (EVG_ABLATE bits, read at evg_create).
+"""Diagnostic: price the phases of the step kernel by skipping them (libevg_diag.so, evg_diag_configure ablate bits).
 bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store.  Not a benchmark."""
 import os
 import sys
@@ -9,8 +9,7 @@ import everglades_amd as evg
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 for abl in (0, 16, 2, 18, 4, 1, 17, 49, 0):
-    os.environ["EVG_ABLATE"] = str(abl)
-    env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True)
+    env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=abl))
     env.reset()
     env.rollout_random(60)
     res = []

@@ -1,57 +1,64 @@
 #!/usr/bin/env python3
 """Turns the output of tools/profile.sh (gpurun_out/prof_<tag>/) into the two files committed under profiles/:
-  <name>_kernel_stats.csv   the rocprofv3 --kernel-trace --stats table, evg kernels only
-  <name>_pmc_traffic.json   HBM bytes per launch / per turn of the step kernel from the FETCH_SIZE and WRITE_SIZE passes,
-                            corrected with the calibration copy of the same passes (tools/pmc_calib.py)
-usage: python tools/pmc_summary.py <tag> <name>      e.g.  r01i r01_i"""
-import csv, glob, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  <name>_kernel_stats.csv   the rocprofv3 --kernel-trace --stats tables of both launch forms (evg kernels only) plus, per form,
+                            the mean duration of the step-kernel dispatches of the timed window (the last 150 turns)
+  <name>_pmc_traffic.json   HBM-side bytes per launch / per env-step of the step kernel from the FETCH_SIZE and WRITE_SIZE
+                            passes, corrected with the calibration copy of the same passes (tools/pmc_calib.py), keyed by the
+                            hash of the kernel sources so that bench.py only uses figures of the build it runs
+usage: python tools/pmc_summary.py <tag> <name> [envs] [workload] [obs_dtype]      e.g.  r02b r02_b"""
+import glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _prof import ROOT, FORMS, FORM_KEY, kernel_source_hash, counter_rows, timed_window, trace_durations
+import csv
 tag, name = sys.argv[1], sys.argv[2]
+ENVS = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "random"
+OBS = sys.argv[5] if len(sys.argv) > 5 else "float32"
 P = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-CMD = "python3 bench.py --steps 150 --warmup 150 --no-cpu-baseline"
+STATE_ROUND_TRIP = 2 * (24 * 4 + 6 * 4 + 6 * 4 + 4 + 4 + 2 * 4)      # words a launch reads at its start and writes at its end, per env (evg_device.h)
 
 
-def counters(sub):
+def calib(sub):
     f = glob.glob(os.path.join(P, sub, "*", "*_counter_collection.csv"))[0]
-    rows = {}
-    for r in csv.DictReader(open(f)):
-        rows.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-    return rows
+    return max(float(r["Counter_Value"]) for r in csv.DictReader(open(f)))     # the 256 MiB copy dominates
 
 
-# kernel stats
-src = glob.glob(os.path.join(P, "stats", "*", "*_kernel_stats.csv"))[0]
-lines = open(src).read().splitlines()
-keep = [lines[0]] + [l for l in lines[1:] if "evg::" in l]
-with open(os.path.join(ROOT, "profiles", name + "_kernel_stats.csv"), "w") as f:
-    f.write('"# rocprofv3 --kernel-trace --stats --output-format csv -- %s (MI355X, 65536 envs). evg_step_kernel<float,64,true,false> = '
-            'persistent form, one launch = 150 turns (warm-up + timed); <float,64,false,false> = the 150 one-launch-per-turn reference leg. '
-            'evg kernels only."\n' % CMD)
-    f.write("\n".join(keep) + "\n")
-
-fe, wr = counters("fetch"), counters("write")
-cf, cw = counters("calib_fetch"), counters("calib_write")
-calib_f = max(max(v) for v in cf.values())          # the 256 MiB copy dominates
-calib_w = max(max(v) for v in cw.values())
-fetch_scale = 262144.0 / calib_f                     # expected KB / reported
-write_scale = 262144.0 / calib_w
-out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- " + CMD,
-       "envs": 65536,
+calib_f, calib_w = calib("calib_fetch"), calib("calib_write")
+fetch_scale, write_scale = 262144.0 / calib_f, 262144.0 / calib_w            # expected KB / reported
+out = {"kernel_source_hash": kernel_source_hash(), "envs": ENVS, "workload": WORKLOAD, "obs_dtype": OBS,
+       "commands": {f: open(os.path.join(P, "cmd_%s.txt" % f)).read().strip().replace(ROOT + "/", "").replace(os.environ.get("GRAFT_REPO_ROOT", "\0") + "/", "") for f in FORMS},
+       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; bytes = FETCH_SIZE KB x fetch_scale + WRITE_SIZE KB x write_scale "
+                 "(the gfx950 correction of MI355X_MICROARCH.md, re-derived by the calibration copy in the same passes); dispatches of the timed window only "
+                 "(desynchronised steady state, bench.py docstring)",
        "calibration": {"copy_256MiB_FETCH_SIZE_KB": calib_f, "copy_256MiB_WRITE_SIZE_KB": calib_w, "expected_KB": 262144,
-                       "fetch_scale": round(fetch_scale, 4), "write_scale": round(write_scale, 4),
-                       "conclusion": "FETCH_SIZE reports 1/2 of the bytes fetched, WRITE_SIZE is exact (tools/pmc_calib.py in the same passes)"},
+                       "fetch_scale": round(fetch_scale, 4), "write_scale": round(write_scale, 4)},
        "forms": {}}
-for form, key in (("persistent", "true, false>"), ("one_launch_per_turn", "false, false>")):
-    kf = [k for k in fe if "evg_step_kernel<float, 64, " + key in k][0]
-    f_kb, w_kb = fe[kf], wr[kf]
-    tpl = 150 if form == "persistent" else 1
+stats_lines = []
+for form, (tail, tpl, nwin) in FORMS.items():
+    fr, fm = counter_rows(os.path.join(P, form + "_fetch"), form)
+    wr, wm = counter_rows(os.path.join(P, form + "_write"), form)
+    f_kb = [r["FETCH_SIZE"] for r in timed_window(fr, form)]
+    w_kb = [r["WRITE_SIZE"] for r in timed_window(wr, form)]
     per_launch = (sum(f_kb) / len(f_kb) * round(fetch_scale) + sum(w_kb) / len(w_kb) * round(write_scale)) * 1024.0
-    out["forms"][form] = {"kernel": kf, "launches": len(f_kb), "turns_per_launch": tpl, "FETCH_SIZE_KB_mean": sum(f_kb) / len(f_kb),
-                          "WRITE_SIZE_KB_mean": sum(w_kb) / len(w_kb), "corrected_bytes_per_launch": per_launch,
-                          "corrected_bytes_per_turn": per_launch / tpl, "bytes_per_env_step": per_launch / tpl / 65536}
-out["corrected_bytes_per_launch"] = out["forms"]["persistent"]["corrected_bytes_per_launch"]
-out["turns_per_launch"] = 150
-out["corrected_bytes_per_turn"] = out["forms"]["persistent"]["corrected_bytes_per_turn"]
+    dur = timed_window(trace_durations(os.path.join(P, form + "_stats"), form), form)
+    mean_ns = sum(dur) / len(dur)
+    bpe = per_launch / tpl / ENVS
+    rt = STATE_ROUND_TRIP if tpl > 1 else 0          # a single-turn launch's figure already contains its round trip
+    out["forms"][FORM_KEY[form]] = {"kernel": fm[-1]["name"], "launches_in_window": len(f_kb), "turns_per_launch": tpl,
+                                    "FETCH_SIZE_KB_mean": sum(f_kb) / len(f_kb), "WRITE_SIZE_KB_mean": sum(w_kb) / len(w_kb),
+                                    "corrected_bytes_per_launch": per_launch, "corrected_bytes_per_turn": per_launch / tpl, "bytes_per_env_step": bpe,
+                                    "state_round_trip_bytes_per_env": rt, "bytes_per_env_step_steady": bpe - rt / tpl,
+                                    "kernel_ns_mean_timed_window": mean_ns, "kernel_us_per_turn": mean_ns / tpl / 1e3,
+                                    "traffic_TBps": per_launch / mean_ns / 1e3, "frac_of_8TBps": per_launch / mean_ns / 1e3 / 8.0,
+                                    "vgpr": fm[-1]["vgpr"], "agpr": fm[-1]["agpr"], "sgpr": fm[-1]["sgpr"], "lds_bytes": fm[-1]["lds"], "scratch": fm[-1]["scratch"]}
+    src = glob.glob(os.path.join(P, form + "_stats", "*", "*_kernel_stats.csv"))[0]
+    lines = open(src).read().splitlines()
+    stats_lines.append('"# %s  --  rocprofv3 --kernel-trace --stats --output-format csv -- %s"' % (FORM_KEY[form], out["commands"][form]))
+    stats_lines.append('"# step kernel, dispatches of the timed window only (last %d of %d): mean %.1f ns = %.2f us per turn; the --stats row below averages ALL '
+                       'dispatches of the run, incl. the 150 one-turn launches of the desynchronising pre-roll (synchronised early-episode positions)"'
+                       % (len(dur), len(trace_durations(os.path.join(P, form + "_stats"), form)), mean_ns, mean_ns / tpl / 1e3))
+    stats_lines += [lines[0]] + [l for l in lines[1:] if "evg::" in l]
+open(os.path.join(ROOT, "profiles", name + "_kernel_stats.csv"), "w").write("\n".join(stats_lines) + "\n")
 json.dump(out, open(os.path.join(ROOT, "profiles", name + "_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out["forms"], indent=1))
 print(open(os.path.join(ROOT, "profiles", name + "_kernel_stats.csv")).read())

@@ -6,7 +6,6 @@ import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["EVG_LIB_PATH"] = os.path.join(ROOT, "everglades-ai-wargame_amd", "libevg_stamps.so")
 import numpy as np
 import torch
 import everglades_amd as evg
@@ -15,7 +14,7 @@ NAMES = ["tables+state load", "orders", "combat0 snapshot", "combat1 worklist", 
          "aggregates+capture", "rewards+stats+reset", "obs build", "state store", "obs write-out", "reset fill"]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 TPL = int(sys.argv[2]) if len(sys.argv) > 2 else 1       # turns per launch (stamps are those of the launch's last turn)
-env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True)
+env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True, library=evg._lib.STAMPS_LIB_PATH)
 env.reset()
 L = env.L
 L.evg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
