@@ -237,6 +237,7 @@ def main():
     env, rollout = make_env(args.obs_dtype)
     stats_dev = env.episode_stats_device()
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
+    evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)   # first use loads torch's small kernels / opens the RCCL channels
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch)
         played += args.warmup

@@ -202,7 +202,6 @@ static void fill_lds_tables(DevTables* D) {
     L.nib[0] = D->p1map_nib;
     for (int p = 0; p < NP; ++p) { L.nib[1 + p] = D->speed_nib[p]; L.nib[3 + p] = D->control_nib[p]; L.nib[5 + p] = D->cost_nib[p]; L.nib[7 + p] = D->type_nib[p]; }
     L.nib[9] = (uint64_t)(uint32_t)D->max_turns | ((uint64_t)(D->damage_nib & 0xFFFFu) << 8) | ((uint64_t)(D->fast_div ? 1u : 0u) << 24);
-    memcpy(L.reset_obs, D->reset_obs, sizeof(L.reset_obs));
 }
 
 static int build_dev_tables(const evg_config* cfg, DevTables* D) {

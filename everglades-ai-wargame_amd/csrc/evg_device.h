@@ -45,8 +45,6 @@ struct __attribute__((aligned(16))) LdsTables {
     int32_t  cp[12], ts[12], res[12];       // control points, team start, resource bits by node ID
     uint32_t init_grp[24], init_node[12];   // state right after game_init (auto-reset inside the kernel)
     uint64_t nib[10];            // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24
-    int16_t  reset_obs[2 * OBS]; // observation of the game_init state, both players
-    int16_t  pad_[6];
 };
 static_assert(sizeof(LdsTables) % 16 == 0, "the kernel copies the blob in 16-byte pieces");
 

@@ -18,6 +18,7 @@
 // Uniform map/unit tables sit in SGPRs as nibble-packed words, per-lane-indexed ones in LDS.
 // No MFMA: there is no dense contraction anywhere on this path.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "evg_device.h"
 #include "evg_rng.h"
 #include "evg_mt.h"
@@ -41,9 +42,29 @@ namespace evg {
         __builtin_amdgcn_sched_barrier(0);                                              \
         if (lane == 0 && io.stamps) io.stamps[(size_t)blockIdx.x * 16 + (i)] = t_;      \
     } while (0)
+// whole-launch stamps of the wave: s_memrealtime (constant 100 MHz) at its start and end plus where it ran (HW_ID, XCC_ID)
+#define STAMP_WAVE_BEGIN() const unsigned long long wave_t0_ = __builtin_amdgcn_s_memrealtime()
+#define STAMP_WAVE_END()                                                                                                   \
+    do {                                                                                                                   \
+        const unsigned long long t1_ = __builtin_amdgcn_s_memrealtime();                                                   \
+        if (threadIdx.x == 0 && A->io_.stamps) {                                                                            \
+            A->io_.stamps[(size_t)blockIdx.x * 16 + 14] = (wave_t0_ & 0xFFFFFFFFull) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32); \
+            A->io_.stamps[(size_t)blockIdx.x * 16 + 15] = (t1_ & 0xFFFFFFFFull) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);      \
+        }                                                                                                                  \
+    } while (0)
 #else
 #define STAMP(i)
+#define STAMP_WAVE_BEGIN()
+#define STAMP_WAVE_END()
 #endif
+
+// Phase markers (stamps build only).  Tried and rejected here: alternating s_setprio between the two wavefronts that share a
+// SIMD.  With equal priority the arbiter favours the older wave (hardware slot 0 finishes a 150-turn launch after 2.31 ms,
+// its partner after 3.04 ms, profiles/r02_c_wave_times.txt); flipping priorities per phase or per turn narrows that gap but
+// leaves the END of the slower wave where it was (3.14 vs 3.14-3.20 ms, profiles/r02_d_wave_times_priority_schemes.txt): the
+// pair's instruction issue is what is saturated (one wave64 VALU instruction per 4 cycles per SIMD), so only fewer
+// instructions make the launch shorter.
+#define PHASE(i) STAMP(i)
 
 // LPW = lanes of the wavefront that own an env side (lane = 2 * env_slot + player): 64 (32 envs per wave) or 32
 // (16 envs per wave; lanes 32..63 are helpers that only join the wave-balanced phases: combat items, write-out).
@@ -74,12 +95,18 @@ struct __align__(16) StepLds {
 // issue order (so do the vector-memory units, per address), so a boundary needs neither s_barrier nor a wait for outstanding
 // global loads/stores (what __syncthreads() would add: s_waitcnt vmcnt(0) stalls every phase behind the turn's
 // observation and health stores): it only has to keep the COMPILER from moving memory accesses across it.
+#if defined(EVG_EXP_SYNC) && EVG_EXP_SYNC == 1          /* experiment builds only (tools/ab.sh) */
+#define WAVE_SYNC() __syncthreads()
+#elif defined(EVG_EXP_SYNC) && EVG_EXP_SYNC == 2
+#define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
 #define WAVE_SYNC()                                            \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
         asm volatile("" ::: "memory");                         \
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
+#endif
 
 // 12-input sorting network (tools/gen_sort12.py: 42 compare-exchanges, verified with the 0-1 principle)
 #define EVG_SORT12_CES(CE) \
@@ -120,23 +147,21 @@ __device__ __forceinline__ void store_obs_vec<int16_t>(int16_t* dst, const int (
 // (agents/State_Machine/random_actions.py:38-46), partial Fisher-Yates on nibble-packed permutations.
 // Same contract as oracle/rng_spec.py random_action_rows.
 __device__ __forceinline__ void gen_random_rows(uint32_t seed_lo, uint32_t seed_hi, uint32_t env_id, uint32_t episode, int turn, int p, int2 (&rows)[NA]) {
-    uint32_t w[16];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const uint4 x = rng_block(seed_lo, seed_hi, env_id, episode, RNG_ACTION, (uint32_t)b, turn, 0, p, 0);
-        w[4 * b] = x.x; w[4 * b + 1] = x.y; w[4 * b + 2] = x.z; w[4 * b + 3] = x.w;
-    }
+    // halves 0..6 of block 0 pick the groups, halves 0..6 of block 1 the nodes (oracle/rng_spec.py)
+    const uint4 xg = rng_block(seed_lo, seed_hi, env_id, episode, RNG_ACTION, 0u, turn, 0, p, 0);
+    const uint4 xn = rng_block(seed_lo, seed_hi, env_id, episode, RNG_ACTION, 1u, turn, 0, p, 0);
+    const uint32_t wg[4] = {xg.x, xg.y, xg.z, xg.w}, wn[4] = {xn.x, xn.y, xn.z, xn.w};
     uint64_t gp = 0xBA9876543210ull;      // nibble i = i
     uint64_t np_ = 0xBA987654321ull;      // nibble i = i + 1
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int j = i + (int)__umulhi(w[i], (uint32_t)(12 - i));
+        const int j = i + (int)(__umul24(rng_half(wg, i), (uint32_t)(12 - i)) >> 16);
         const uint64_t x = ((gp >> (4 * i)) ^ (gp >> (4 * j))) & 15ull;
         gp ^= (x << (4 * i)) ^ (x << (4 * j));
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int j = i + (int)__umulhi(w[8 + i], (uint32_t)(11 - i));
+        const int j = i + (int)(__umul24(rng_half(wn, i), (uint32_t)(11 - i)) >> 16);
         const uint64_t x = ((np_ >> (4 * i)) ^ (np_ >> (4 * j))) & 15ull;
         np_ ^= (x << (4 * i)) ^ (x << (4 * j));
     }
@@ -322,6 +347,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int EPW = LPW / 2;                        // envs per wavefront
     constexpr int DP_CAP = CombatLds<LPW>::DP_CAP;
     __shared__ StepLds<LPW> L;
+    // 8 workgroups per CU (2 waves per SIMD) keep a whole 65 536-env batch resident: 160 KiB / 8 = 20 480 B each
+    static_assert(sizeof(StepLds<LPW>) <= 20480, "step kernel LDS exceeds the 8-workgroups-per-CU budget");
     const int lane = threadIdx.x;
     const bool envlane = LPW == WG || lane < LPW;       // owns an env side; helper lanes only join the balanced phases
     const int E = envlane ? lane >> 1 : 0, P = lane & 1;
@@ -333,10 +360,16 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const DevTables* T = S.T;
 
     STAMP(0);
+    STAMP_WAVE_BEGIN();
+#ifdef EVG_DIAG
+    const int kStaggerSleeps = (A->io_.ablate >> 8) & 0xFFu ? (int)((A->io_.ablate >> 8) & 0xFFu) - 1 : 20;   // experiment knob (tools/stagger.py): n - 1 x 256 cycles
+#else
+    constexpr int kStaggerSleeps = 20;                      // x 256 cycles (s_sleep 4)
+#endif
     // ---- prologue loads: the constant tables (one blob, already in its LDS layout) and this lane's state (env fastest; the two player rows of a group index interleave
     // across lanes).  Every load is issued before the first LDS store, so the launch pays ONE memory round trip here
     // instead of one per table and one for the state.
-    constexpr int TV = (int)(sizeof(LdsTables) / 16);   // 104 16-byte pieces: two loads per lane
+    constexpr int TV = (int)(sizeof(LdsTables) / 16);   // 77 16-byte pieces: two loads per lane
     static_assert(TV > WG && TV <= 2 * WG, "table blob is copied in two rounds");
     const uint4* timg = reinterpret_cast<const uint4*>(&T->lds);
     const uint4 tv0 = timg[lane], tv1 = timg[lane + WG < TV ? lane + WG : 0];
@@ -365,6 +398,16 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     int turn = (int)(envw & 0xFFu);
     int status = (int)((envw >> 8) & 3u);
+    if constexpr (!MULTI) {
+        // Single-turn launches: all 2 048 wavefronts start together and every SIMD's two waves would run the same phases in
+        // lockstep, competing for the same issue slots phase by phase.  The wave in hardware slot 1 therefore waits STAGGER
+        // cycles here, with its loads already in flight (tools/stagger.py: 35.0 -> 32.6 us per launch at 65 536 envs) ...
+        if (__builtin_amdgcn_s_getreg(6148) & 1u)            // HW_ID.wave_id: the wave's slot on its SIMD
+            for (int i = 0; i < kStaggerSleeps; ++i) __builtin_amdgcn_s_sleep(4);
+        // ... and the orders this kernel draws itself need only the turn and the episode (the first two loads), so they are
+        // drawn while the group / node words are still on their way
+        if (io.gen_actions == 1) gen_random_rows(S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, turn, P, act_in);
+    }
     {
         uint4* lt = reinterpret_cast<uint4*>(&L.tab);
         lt[lane] = tv0;
@@ -397,7 +440,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int lane_ = threadIdx.x;
     if (MULTI) { asm volatile("" : "+s"(A)); asm volatile("" : "+v"(lane_)); T = S.T; }
     const int lane = lane_;
-    if (MULTI) STAMP(0);                                // diagnostic build: the stamps of a launch are those of its last turn
+    if (MULTI) PHASE(0);                                // diagnostic build: the stamps of a launch are those of its last turn
     const bool envlane = LPW == WG || lane < LPW;
     const int E = envlane ? lane >> 1 : 0, P = lane & 1;
     const int col = envlane ? lane : 0;                 // LDS column (helpers never write; their reads are discarded)
@@ -413,7 +456,12 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int2 act[NA];
     if (io.gen_actions) {
         if (io.gen_actions == 1) {
-            gen_random_rows(S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, turn, P, act);
+            if constexpr (MULTI) {
+                gen_random_rows(S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, turn, P, act);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) act[i] = act_in[i];         // drawn in the prologue, under the state loads
+            }
         } else {                                        // on-device scripted agents of both seats (evg_rollout_policies, fused)
             const ChipView<LPW> view{&L, col, E, P, turn, p1nib};
             agent_rows(P ? io.policy1 : io.policy0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, true, status == 0,
@@ -432,7 +480,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int i = 0; i < NA; ++i) act[i] = act_in[i];             // loaded in the prologue (single-turn form only)
     }
-    STAMP(1);
+    PHASE(1);
 
     const bool frozen = status != 0;                    // finished, not auto-reset: repeat terminal outputs
     const bool play = valid && !frozen && !observe_only;
@@ -444,7 +492,25 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // of every row can be taken from the pre-order words; rows interact only through test 1 (an id already
         // commanded this turn) and, for aliased ids, through the order of the writes (the later row wins, as in
         // the reference).  That makes the 7 LDS lookups independent instead of a 7-deep dependent chain.
-        if (!ABLATED(1u)) {
+        if (!ABLATED(1u) && io.gen_actions == 1) {
+            // Orders drawn in this kernel by gen_random_rows: 7 DISTINCT group ids in 0..11 and node ids in 1..11 by construction, so
+            // the domain checks, the Python-list negative indices and the "already commanded this turn" test of the general path
+            // below cannot trigger; every row is independent.
+            uint32_t wv[NA], nv[NA], dv[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                nv[i] = P ? (uint32_t)((p1nib >> (4 * act[i].y)) & 15u) : (uint32_t)act[i].y;       // :233-234
+                wv[i] = L.G[act[i].x][lane];
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) dv[i] = (uint32_t)((L.tab.adj[wv[i] & G_LOC_M] >> (4 * nv[i])) & 15u);   // :245-250
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const uint32_t w = wv[i];
+                if (((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING && dv[i] != 0)                       // :243, :267-270
+                    L.G[act[i].x][lane] = (w & ~(G_DEST_M | G_DIST_M | G_MODE_M)) | (nv[i] << G_DEST_S) | (dv[i] << G_DIST_S) | (MODE_READY << G_MODE_S);
+            }
+        } else if (!ABLATED(1u)) {
             int gidv[NA], nidv[NA], rawv[NA];
             uint32_t wv[NA], dv[NA];
             bool okv[NA];
@@ -477,7 +543,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
     }
-    STAMP(2);
+    PHASE(2);
 
     // ---------------- combat (server.py:503-654)
     // Stage 0 (lane = env side): pre-combat snapshot.  A group fights at its node if it is alive and not moving
@@ -536,11 +602,14 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 ndw += (int)((((aw >> ((n & 3u) * 8)) & 0xFFu) + 3u) >> 2);
             }
         }
-        STAMP(3);
+        PHASE(3);
 
-        // Stage 1: wave-wide work list (one item per fighting group) and damage-pool layout, by prefix scan
-        const int nfight = __popc(fmask);
-        int incl = (ndw << 16) | nfight;                  // both counts in one scan: totals stay below 2^16 (<= 768 items, <= 2112 words)
+        // Stage 1: wave-wide work list (one item per fighting group) and damage-pool layout, by prefix scan.  The items of the
+        // 12-unit group (gid 11) are listed AFTER all others: only that group needs a second block of draws (more than 8 units)
+        // and the health slots 8..11, so every round of 64 items but the last runs the short 8-unit code.
+        const int nf_a = __popc(fmask & 0x7FFu), nf_b = (int)((fmask >> 11) & 1u);
+        const int packed = nf_a | (nf_b << 10) | (ndw << 17);   // three counts in one scan: <= 704 items (10 bits), <= 64 (7 bits), <= 2112 words (12 bits)
+        int incl = packed;
         // inclusive scan over the 64 lanes in registers: log-steps inside each row of 16 lanes (DPP row_shr, zero fill),
         // then the row totals are carried across rows (DPP row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);
@@ -549,26 +618,29 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
-        const int excl = incl - ((ndw << 16) | nfight);
+        const int excl = incl - packed;
         const int tot = __builtin_amdgcn_readlane(incl, WG - 1), mid = __builtin_amdgcn_readlane(excl, LPW / 2);
-        const int excl_i = excl & 0xFFFF, excl_d = excl >> 16, tot_i = tot & 0xFFFF, tot_d = tot >> 16, mid_i = mid & 0xFFFF, mid_d = mid >> 16;
+        const int excl_a = excl & 0x3FF, excl_b = (excl >> 10) & 0x7F, excl_d = excl >> 17;
+        const int tot_a = tot & 0x3FF, tot_b = (tot >> 10) & 0x7F, tot_d = tot >> 17, mid_a = mid & 0x3FF, mid_b = (mid >> 10) & 0x7F, mid_d = mid >> 17;
         // the pool holds every fight of the wave in the common case; otherwise two passes of 16 envs each
         const int npass = tot_d <= DP_CAP ? 1 : 2;
         const uint32_t dmg_nib = (misc >> 8) & 0xFFFFu;
         const bool fast_div = ((misc >> 24) & 1u) != 0;
         for (int ps = 0; ps < npass; ++ps) {
             const bool inpass = npass == 1 || (lane / (LPW / 2)) == ps;     // helper lanes own no items
-            const int ref_i = (npass == 2 && ps == 1) ? mid_i : 0, ref_d = (npass == 2 && ps == 1) ? mid_d : 0;
-            const int end_i = (npass == 2 && ps == 0) ? mid_i : tot_i, end_d = (npass == 2 && ps == 0) ? mid_d : tot_d;
-            const int nitems = end_i - ref_i, ndwords = end_d - ref_d;
+            const bool second = npass == 2 && ps == 1, first = npass == 2 && ps == 0;
+            const int ref_a = second ? mid_a : 0, ref_b = second ? mid_b : 0, ref_d = second ? mid_d : 0;
+            const int end_a = first ? mid_a : tot_a, end_b = first ? mid_b : tot_b, end_d = first ? mid_d : tot_d;
+            const int na = end_a - ref_a, nitems = na + (end_b - ref_b), ndwords = end_d - ref_d;
             if (inpass) {
-                int wi = excl_i - ref_i;
-                uint32_t f = fmask;
+                int wi = excl_a - ref_a;
+                uint32_t f = fmask & 0x7FFu;
                 while (f) {
                     const uint32_t gid = (uint32_t)__ffs(f) - 1u;
                     f &= f - 1;
                     L.u.c.W[wi++] = (uint16_t)((uint32_t)lane | (gid << 6));
                 }
+                if (nf_b) L.u.c.W[na + excl_b - ref_b] = (uint16_t)((uint32_t)lane | (11u << 6));
                 int doff = excl_d - ref_d;
                 uint32_t c = contested;
                 while (c) {
@@ -582,7 +654,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             for (int i = lane; i < ndwords; i += WG) L.u.c.DP[i] = 0;
             WAVE_SYNC();
-            STAMP(4);
+            PHASE(4);
 
             // health row of this lane's first item: issued now, consumed in phase B, so that the HBM latency hides
             // behind the draws (a fighting group is very likely to be hit; 64-96 B per group)
@@ -655,13 +727,13 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const uint32_t dmg = (dmg_nib >> (4 * type)) & 15u;
                 const int turn_e = (int)L.u.c.TURN[SL];
                 const uint32_t epi_e = L.u.c.EPI[SL], env_id_e = id_base + (uint32_t)(SL >> 1);
-                for (int b = 0; b * 4 < cnt; ++b) {
+                for (int b = 0; b * 8 < cnt; ++b) {               // one block = eight 16-bit draws: a second one only for the 12-unit group
                     const uint4 x = rng_block(seed_lo, seed_hi, env_id_e, epi_e, RNG_COMBAT, (uint32_t)b, turn_e, node, side, gid);
                     const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (b * 4 + i < cnt) {
-                            const uint32_t uid = __umulhi(xs[i], tot_o);                                // :562
+                    for (int i = 0; i < 8; ++i) {
+                        if (b * 8 + i < cnt) {
+                            const uint32_t uid = __umul24(rng_half(xs, i), tot_o) >> 16;                // :562 (tot_o <= 100)
                             atomicAdd(&L.u.c.DP[doff_o + (uid >> 2)], dmg << (8 * (uid & 3u)));         // :563-566
                         }
                     }
@@ -669,7 +741,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             }
             WAVE_SYNC();
-            STAMP(5);
+            PHASE(5);
 
             // Phase B (:573-644): one lane per fighting group; the uid-th alive unit of the snapshot (list-order
             // prefix + rank among the group's alive slots) takes its summed damage.  Both directions read only
@@ -688,16 +760,17 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 uint32_t dw[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dw[q] = L.u.c.DP[min(w0i + (uint32_t)q, (uint32_t)(DP_CAP - 1))];
-                const uint64_t dlo = (uint64_t)dw[0] | ((uint64_t)dw[1] << 32), dhi = (uint64_t)dw[2] | ((uint64_t)dw[3] << 32);
-                uint32_t dmv[12], any = 0;
-#pragma unroll
-                for (int sl = 0; sl < 12; ++sl) {            // rank of slot sl among the alive slots: no dependent chain, no branches
-                    const uint32_t b = sh0 + (uint32_t)__popc(mask & ((1u << sl) - 1u));               // byte of the run, 0..14
-                    const uint32_t v = (uint32_t)((b < 8u ? dlo : dhi) >> (8u * (b & 7u))) & 0xFFu;
-                    dmv[sl] = ((mask >> sl) & 1u) ? v : 0u;
-                    any |= dmv[sl];
+                // align the run to byte 0 (v_alignbyte_b32) and clear what lies beyond the group's own `cnt` bytes (the next
+                // group's damage): byte r of {a0, a1, a2} is then the damage of the group's r-th alive unit
+                const uint32_t cnt = (uint32_t)__popc(mask);                                          // 1..12
+                uint32_t a0 = __builtin_amdgcn_alignbyte(dw[1], dw[0], sh0), a1 = __builtin_amdgcn_alignbyte(dw[2], dw[1], sh0);
+                uint32_t a2 = __builtin_amdgcn_alignbyte(dw[3], dw[2], sh0);
+                {
+                    const uint64_t keep = cnt >= 8u ? ~0ull : ((1ull << (8u * cnt)) - 1ull);
+                    a0 &= (uint32_t)keep; a1 &= (uint32_t)(keep >> 32);
+                    a2 = cnt > 8u ? (cnt >= 12u ? a2 : (a2 & ((1u << (8u * (cnt - 8u))) - 1u))) : 0u;
                 }
-                if (any) {
+                if ((a0 | a1 | a2) != 0u) {
                     double* row = S.health + (size_t)(e0 + (SL >> 1)) * (2 * NU) + side * NU + gid * 8;
                     double h[12];
                     if (kPrefetch && it < WG) {                     // first round: prefetched before the draws
@@ -719,28 +792,41 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const int ctrl_by = (int)((L.NW[node][SL >> 1] >> 10) & 3u) - 1;
                     const int di = (int)type * 12 + (ctrl_by == side ? node : 0);                    // :592-597 (fort bonus dead)
                     const double denom = L.tab.den[di], rcp = L.tab.rcp[di];
-                    uint32_t newmask = mask;
-                    if (fast_div) {
-#pragma unroll
-                        for (int sl = 0; sl < 12; ++sl) {        // unconditional: an untouched unit loses exactly 0.0
-                            const double a = (double)(10u * dmv[sl]);                                 // exact, like 10. * tgt_dmg
-                            const double q0 = a * rcp;
-                            const double loss = __builtin_fma(__builtin_fma(-denom, q0, a), rcp, q0); // == a / denom (DevTables::fast_div)
-                            double hv = h[sl] - loss;                                                 // :609
+                    // Slot sl holds the unit of rank popc(mask below sl); its damage byte is picked with one v_perm_b32 (selector =
+                    // rank, the other three selector bytes 0x0C = constant zero).  A slot whose unit is already dead picks the byte
+                    // of the next alive unit: harmless, its health is 0.0 and stays 0.0 (0 - loss clamps to 0), its mask bit stays clear.
+                    uint32_t deadmask = 0;
+                    auto apply_hits = [&](auto fast) {           // one straight-line body per quotient form (wave-uniform choice)
+                        auto hit = [&](int sl, uint32_t d) {
+                            double loss;
+                            if constexpr (decltype(fast)::value) {
+                                const double a = (double)__umul24(10u, d);                            // exact, like 10. * tgt_dmg (d is one byte)
+                                const double q0 = a * rcp;
+                                loss = __builtin_fma(__builtin_fma(-denom, q0, a), rcp, q0);          // == a / denom (DevTables::fast_div)
+                            } else {
+                                loss = (10.0 * (double)d) / denom;                                    // :601
+                            }
+                            const double hv = h[sl] - loss;                                           // :609
                             const bool dead = hv <= 0.0;                                              // :615-618
                             h[sl] = dead ? 0.0 : hv;
-                            newmask &= dead ? ~(1u << sl) : ~0u;
-                        }
-                    } else {
+                            deadmask |= dead ? (1u << sl) : 0u;
+                        };
 #pragma unroll
-                        for (int sl = 0; sl < 12; ++sl) {
-                            const double loss = (10.0 * (double)dmv[sl]) / denom;                     // :601
-                            double hv = h[sl] - loss;
-                            const bool dead = hv <= 0.0;
-                            h[sl] = dead ? 0.0 : hv;
-                            newmask &= dead ? ~(1u << sl) : ~0u;
+                        for (int sl = 0; sl < 8; ++sl) {         // rank <= sl < 8: bytes of a0, a1
+                            const uint32_t sel = (uint32_t)__popc(mask & ((1u << sl) - 1u)) | 0x0C0C0C00u;
+                            hit(sl, __builtin_amdgcn_perm(a1, a0, sel));
                         }
-                    }
+                        if (gid == 11) {                         // the 12-unit group: slots 8..11, ranks up to 11
+#pragma unroll
+                            for (int sl = 8; sl < 12; ++sl) {
+                                const uint32_t rank = (uint32_t)__popc(mask & ((1u << sl) - 1u));
+                                const uint32_t dA = __builtin_amdgcn_perm(a1, a0, rank | 0x0C0C0C00u), dB = __builtin_amdgcn_perm(0u, a2, (rank - 8u) | 0x0C0C0C00u);
+                                hit(sl, rank < 8u ? dA : dB);
+                            }
+                        }
+                    };
+                    if (fast_div) apply_hits(std::true_type{}); else apply_hits(std::false_type{});
+                    const uint32_t newmask = mask & ~deadmask;
                     double2* w2 = reinterpret_cast<double2*>(row);
 #pragma unroll
                     for (int sl = 0; sl < 4; ++sl) w2[sl] = make_double2(h[2 * sl], h[2 * sl + 1]);
@@ -759,7 +845,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             WAVE_SYNC();
         }
     }
-    STAMP(6);
+    PHASE(6);
 
     // ---------------- movement of this lane's groups (server.py:656-706), branch-free
     uint32_t gw[12];
@@ -784,7 +870,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             gw[k] = nw_;
         }
     }
-    STAMP(7);
+    PHASE(7);
 
     // ---------------- per-node aggregates of this side (post-movement): capture points | units listed << 16
     if (envlane) {
@@ -861,7 +947,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         else if (base_cap) status = EVG_BASE_CAPTURE;                              // :327
         if (MT && mt_lane && turn % 10 == 0) (void)mt_randint(mt, 2u * NG + 1u);    // :337-338 focus draw: unobservable, but it consumes output
     }
-    STAMP(8);
+    PHASE(8);
 
     // ---------------- reward / done / winner (everglades_env.py:37-61, evaluate.py:155-160)
     float rew0, rew1;
@@ -936,25 +1022,25 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     WAVE_SYNC();        // node words final; everybody is done adding to A
-    STAMP(9);
+    PHASE(9);
 
     // ---------------- observation of this lane's player (board_state :382-455, player_state :457-501,
     // everglades_env.py:158-171), written as int16 straight into the wave's output image in LDS
     int cs_s[12], ou_s[12];
+    // an env that starts a new episode shows the game_init position (gw and the node words already hold it): the whole opposing
+    // army stands on its own base.  Branch-free (masks), so that the 22 LDS reads below stay one batch.
+    const uint32_t keep_units = do_reset ? 0u : ~0u;
+    const uint32_t opp_base = do_reset ? (L.tab.init_grp[(1 - P) * 12] & G_LOC_M) : 0xFFu;              // 0xFF: no such node
 #pragma unroll
     for (int i = 1; i <= NN; ++i) {
         const int n = P ? (int)((p1nib >> (4 * i)) & 15u) : i;                    // slot i of player 1 shows node p1_node_map[i] (:437-439)
         cs_s[i] = (int)(L.NW[n][E] & 0x3FFu) - 512;                               // control sign not mirrored
-        ou_s[i] = (int)(L.u.A[n][col ^ 1] >> 16);                                // opposing units listed at the node, moving ones included
+        const uint32_t listed = L.u.A[n][col ^ 1] >> 16;                         // opposing units listed at the node, moving ones included
+        ou_s[i] = (int)((listed & keep_units) | ((uint32_t)n == opp_base ? (uint32_t)NU : 0u));
     }
     WAVE_SYNC();        // A is dead from here on: the union becomes the output image
     int16_t* orow = &L.u.O[col * OBS];
-    if (!envlane) {
-        // helper lane: nothing to write
-    } else if (do_reset) {
-#pragma unroll
-        for (int i = 0; i < OBS; ++i) orow[i] = L.tab.reset_obs[P * OBS + i];
-    } else {
+    if (envlane) {
         orow[0] = (int16_t)turn;
 #pragma unroll
         for (int i = 1; i <= NN; ++i) {
@@ -977,7 +1063,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             o[4] = (int16_t)__popc(w & G_MASK_M);
         }
     }
-    STAMP(10);
+    PHASE(10);
 
     // ---------------- store state (coalesced)
     // (multi-turn form: the state lives on chip between turns and goes back to HBM after the launch's last turn)
@@ -1003,7 +1089,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int k = 0; k < 12; ++k) L.G[k][lane] = gw[k];
     }
     WAVE_SYNC();             // output image complete
-    STAMP(11);
+    PHASE(11);
 
     // ---------------- observation write-out: the wave's 32 x 210 values are contiguous in the output; every lane
     // converts 16 bytes' worth per iteration (conflict-free LDS reads, fully coalesced 1 KiB stores per wave)
@@ -1060,7 +1146,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
     }
-    STAMP(12);
+    PHASE(12);
 
     // ---------------- health of envs that start a new episode: 1600 B each, written by the whole wave
     uint64_t rm = __ballot(do_reset && P == 0);        // do_reset is false on helper lanes
@@ -1070,9 +1156,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         double2* dst = reinterpret_cast<double2*>(S.health + (size_t)(e0 + (l >> 1)) * (2 * NU));
         for (int i = lane; i < NU; i += WG) dst[i] = make_double2(100.0, 100.0);
     }
-    STAMP(13);
+    PHASE(13);
     if (MULTI) WAVE_SYNC();                             // next turn's LDS traffic stays behind this turn's (global accesses of one wave are issued in order)
     }   // turns
+    STAMP_WAVE_END();
 }
 
 #undef S

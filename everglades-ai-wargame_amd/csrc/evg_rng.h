@@ -33,4 +33,8 @@ __device__ __forceinline__ uint4 rng_block(uint32_t seed_lo, uint32_t seed_hi, u
     return philox4x32_10(ctr, seed_lo, seed_hi);
 }
 
+// the eight 16-bit draws of a block (oracle/rng_spec.py `halves`): half h = bits 16*(h & 1) .. +15 of word h >> 1; h is a
+// compile-time constant at every call site
+__device__ __forceinline__ uint32_t rng_half(const uint32_t (&w)[4], int h) { return (h & 1) ? (w[h >> 1] >> 16) : (w[h >> 1] & 0xFFFFu); }
+
 }  // namespace evg

@@ -15,14 +15,20 @@ Generator: Philox4x32-10 (Salmon et al., SC'11), 64-bit key, 128-bit counter.
   counter = (block | domain << 28,  turn | node << 8 | player << 12 | group << 16,  episode,
              env_id & 0xffffffff)
 
+  A block's four 32-bit words are used as EIGHT 16-bit draws ("halves"): half h of a block is bits
+  16*(h & 1) .. 16*(h & 1) + 15 of word h >> 1.  A draw below n is (half * n) >> 16; n never exceeds 100
+  here, so the deviation from uniform stays below n / 65536 = 0.15 % -- and one Philox block (the expensive
+  part on the device) serves a whole 8-unit group instead of half of it.
+
   combat  (domain 0): the j-th alive unit (j = the loop index of server.py:561) of attacking group
-                      `group` of `player` at `node` on `turn` uses word (j & 3) of block (j >> 2);
-                      target index uid = (word * n) >> 32 with n = opposing alive units at the node.
+                      `group` of `player` at `node` on `turn` uses half (j & 7) of block (j >> 3);
+                      target index uid = (half * n) >> 16 with n = opposing alive units at the node.
                       (Keyed by group and unit, not by a node-wide ordinal, so that a GPU lane can
                       draw for its group without knowing the groups listed before it.)
   actions (domain 1): the on-device stand-in for agents/State_Machine/random_actions.py:38-46
-                      (7 distinct groups of 12, 7 distinct nodes of 1..11): blocks 0..3 give 16
-                      words; partial Fisher-Yates, see `random_action_rows`.
+                      (7 distinct groups of 12, 7 distinct nodes of 1..11): halves 0..6 of block 0 pick
+                      the groups, halves 0..6 of block 1 the nodes; partial Fisher-Yates, see
+                      `random_action_rows`.
   swarm   (domain 2): shuffle of the SwarmAgent attack list (swarm_agent.py:86-87), see agents.
   delay   (domain 3): the `random.random() > 0.68` coin of random_actions_delay.py: word 0 of block 0 as a
                       fraction of 2^32.
@@ -60,24 +66,28 @@ def _ctr(domain, block, turn, node, player, episode, env_id, group=0):
             env_id & MASK)
 
 
+def halves(words):
+    """The eight 16-bit draws of one block."""
+    return [(words[h >> 1] >> (16 * (h & 1))) & 0xFFFF for h in range(8)]
+
+
 def combat_draw(seed, env_id, episode, turn, node, player, group, j, n):
     """Target index in [0, n) for the j-th alive unit of attacking `group` (see module docstring)."""
-    w = philox4x32_10(_ctr(DOMAIN_COMBAT, j >> 2, turn, node, player, episode, env_id, group), _key(seed))
-    return (w[j & 3] * int(n)) >> 32
+    w = philox4x32_10(_ctr(DOMAIN_COMBAT, j >> 3, turn, node, player, episode, env_id, group), _key(seed))
+    return (halves(w)[j & 7] * int(n)) >> 16
 
 
 def random_action_rows(seed, env_id, episode, turn, player):
     """7 rows (group, node) -- distinct groups from 0..11, distinct nodes from 1..11 (player's own numbering)."""
-    words = []
-    for b in range(4):
-        words += philox4x32_10(_ctr(DOMAIN_ACTION, b, turn, 0, player, episode, env_id), _key(seed))
+    hg = halves(philox4x32_10(_ctr(DOMAIN_ACTION, 0, turn, 0, player, episode, env_id), _key(seed)))
+    hn = halves(philox4x32_10(_ctr(DOMAIN_ACTION, 1, turn, 0, player, episode, env_id), _key(seed)))
     g = list(range(12))
     n = list(range(1, 12))
     for i in range(7):
-        j = i + ((words[i] * (12 - i)) >> 32)
+        j = i + ((hg[i] * (12 - i)) >> 16)
         g[i], g[j] = g[j], g[i]
     for i in range(7):
-        j = i + ((words[8 + i] * (11 - i)) >> 32)
+        j = i + ((hn[i] * (11 - i)) >> 16)
         n[i], n[j] = n[j], n[i]
     return [(g[i], n[i]) for i in range(7)]
 

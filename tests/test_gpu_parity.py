@@ -3,6 +3,8 @@
 reference and (b) the CPU oracle on the same seeded inputs.  Bit-exact for every integer
 (observations, scores, status, packed state) and for float64 health; float32 rewards within 1e-6
 of the oracle's float64 (tolerance of BASELINE.json north_star: 1e-5)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -794,3 +796,258 @@ def test_long_soak_persistent_vs_oracle(evg, oracle_mod):
     tot = env.episode_stats()["totals"]
     assert tot[0] == tot[1] + tot[2] + tot[3] and tot[0] >= 20 * N
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: the north-star acceptance sample, whole-batch comparisons at the headline size, the ABI's error paths on a box
+# that has a device, and the HIP path sharded over processes
+# ---------------------------------------------------------------------------------------------------------------
+def test_ten_thousand_reference_matches_on_device(evg):
+    """BASELINE north_star: bit-identical win counts vs the CPU reference over 10 000 seeded matches.  ONE 10 000-env handle plays
+    env ids 0..9999 of tests/golden/matches_10k.npz (games played by the imported reference) in the persistent form -- a single
+    launch of 150 turns, finished games frozen -- and reproduces every game: length, final scores, status, terminal rewards,
+    winner, episode returns, the checksums of both final observations, units alive; hence the win/tie counts, bit for bit."""
+    from test_oracle_golden import check_matches
+    d = load_golden("matches_10k.npz")
+    n = len(d["length"])
+    env = evg.EvergladesVecEnv(n, seed=int(d["seed"][0]), env_id_base=0, obs_dtype="float64", auto_reset=False)
+    env.reset()
+    obs, rew, done, info = env.rollout_random(150, turns_per_launch=150)
+    assert int(done.sum()) == n
+    st = env.episode_stats()
+    o = _np(obs)
+    got = dict(length=st["length"].astype(np.int16), scores=_np(info["scores"]), status=_np(info["status"]), reward=_np(rew).astype(np.float64),
+               returns=st["returns"].astype(np.float64), winner=st["winner"], obs_final_sum=o.sum(axis=2).astype(np.int32),
+               alive_final=o[:, :, 49::5].sum(axis=2).astype(np.int16))
+    assert np.array_equal(_np(info["winner"]), d["winner"])
+    check_matches(got, d)
+    assert st["totals"].tolist() == [n] + d["wins_p0_p1_tie"].tolist()
+    env.close()
+    # the same games one launch per turn through evg_step, on a second handle: identical outcome
+    env = evg.EvergladesVecEnv(n, seed=int(d["seed"][0]), env_id_base=0, auto_reset=False)
+    env.reset()
+    for _ in range(150):
+        obs, rew, done, info = env.step(env.random_actions())
+    st2 = env.episode_stats()
+    assert np.array_equal(st2["winner"], d["winner"]) and np.array_equal(st2["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"])
+    env.close()
+
+
+def _compare_whole_batch(env, ora, o_obs, what):
+    """every env of the batch: packed state (groups incl. arrival stamps, nodes, float64 health, turn/status/episode), observations and
+    the results of the last finished episode"""
+    s, os_ = env.get_state(), ora.get_state()
+    for k in ("groups", "nodes", "health", "env"):
+        assert np.array_equal(s[k], os_[k]), (what, k, int((s[k] != os_[k]).reshape(len(s[k]), -1).any(axis=1).sum()), "envs differ")
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs), (what, "observations")
+    st, ost = env.episode_stats(), ora.episode_stats()
+    assert np.array_equal(st["winner"], ost["winner"]) and np.array_equal(st["length"], ost["length"]) and np.array_equal(st["totals"], ost["totals"]), what
+    assert np.allclose(st["returns"], ost["returns"], rtol=0, atol=1e-4), what
+
+
+@pytest.mark.parametrize("form", ["persistent", "one_launch_per_turn"])
+def test_config3_whole_batch_vs_oracle(evg, oracle_mod, form):
+    """BASELINE config 3 (65 536 concurrent games, random vs random, auto-reset) compared with the oracle on ALL 65 536 envs --
+    not a window: after 310 turns (two resets per env) the final packed state incl. float64 health, the observations, the orders of
+    the last turn and the per-env episode results are bit-equal, in both launch forms of the step kernel."""
+    N, seed, steps = 65536, 90210, 310
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset(); ora.reset()
+    env.rollout_random(steps, turns_per_launch=150 if form == "persistent" else 1)
+    for t in range(steps - 1):
+        ora.step_noobs(ora.random_actions())
+    a = ora.random_actions()
+    o_obs, _, _, _ = ora.step(a)
+    assert np.array_equal(_np(env._actions), a), "orders of the last turn"
+    _compare_whole_batch(env, ora, o_obs, form)
+    env.close()
+
+
+def test_config5_whole_batch_vs_oracle(evg, oracle_mod):
+    """BASELINE config 5 (65 536 games, Cycle_BRush_Turn25 vs SwarmAgent fused into the step kernel, persistent form, auto-reset;
+    games end by BaseCapture after 84-94 turns so the envs desynchronise) compared with the oracle's agents + env on ALL envs."""
+    N, seed, steps = 65536, 515, 200
+    seats = ("cycle_rush_turn25", "swarm")
+    pid = [evg.EvergladesVecEnv.POLICIES[s] for s in seats]
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset()
+    o_obs = ora.reset()
+    env.rollout_policies(steps, seats[0], seats[1], fused=True, turns_per_launch=150)
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(steps):
+        ora.scripted_actions(pid[0], 0, o_obs, oa)
+        ora.scripted_actions(pid[1], 1, o_obs, oa)
+        o_obs, _, _, _ = ora.step(oa)
+    assert np.array_equal(_np(env._actions), oa), "orders of the last turn"
+    _compare_whole_batch(env, ora, o_obs, "config5")
+    assert env.episode_stats()["totals"][0] >= 2 * N
+    env.close()
+
+
+def test_abi_error_paths_on_a_device(evg):
+    """SURVEY 8(b) "Errors": with a device present, every misuse of the C-ABI comes back as a negative status plus a message --
+    no crash, no exception across the ABI, no effect on a live handle."""
+    import ctypes as C
+    lib = evg.load_library()
+    L = evg._lib
+
+    def cfg_default(**kw):
+        cfg = L.EvgConfig()
+        cfg.struct_size, cfg.abi_version, cfg.num_envs, cfg.device_id = C.sizeof(L.EvgConfig), L.ABI_VERSION, 8, 0
+        cfg.tables = evg.default_tables()
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        return cfg
+
+    def create(cfg):
+        h = C.c_void_p()
+        rc = lib.evg_create(C.byref(cfg), C.byref(h))
+        assert (rc == 0) == bool(h.value)
+        return rc, h, lib.evg_last_error().decode()
+
+    for bad in (dict(struct_size=12), dict(abi_version=L.ABI_VERSION + 7), dict(num_envs=0), dict(num_envs=-5), dict(obs_dtype=9), dict(rng_mode=5),
+                dict(env_id_base=2 ** 32 - 3), dict(env_id_base=2 ** 50)):
+        rc, h, msg = create(cfg_default(**bad))
+        assert rc == -1 and msg, bad                                  # EVG_ERR_INVALID
+    rc, h, msg = create(cfg_default(device_id=1000))
+    assert rc == -2 and "device" in msg                               # EVG_ERR_NO_DEVICE
+
+    def table_case(edit):
+        cfg = cfg_default()
+        edit(cfg.tables)
+        return create(cfg)
+
+    def set_dist(t): t.node_dist[1][2] = 9
+    def set_diag(t): t.node_dist[3][3] = 2
+    def set_cp(t): t.node_control_points[5] = 600
+    def set_def(t): t.node_defense[4] = -1.0
+    def set_start(t): t.node_team_start[3] = 0
+    def set_map(t): t.p1_node_map[2] = 11
+    def set_types(t): t.num_unit_types = 7
+    def set_dmg(t): t.unit_damage[1] = 40
+    def set_gt(t): t.group_type[1][3] = 3
+    def set_size(t): t.group_size[0][0] = 10
+    def set_turns(t): t.max_turns = 400
+    for edit in (set_dist, set_diag, set_cp, set_def, set_start, set_map, set_types, set_dmg, set_gt, set_size, set_turns):
+        rc, h, msg = table_case(edit)
+        assert rc == -1 and msg, edit.__name__
+    assert lib.evg_create(None, None) == -1
+
+    rc, h, msg = create(cfg_default())
+    assert rc == 0, msg
+    try:
+        import torch
+        obs = torch.zeros((8, 2, 105), device="cuda")
+        act = torch.zeros((8, 2, 7, 2), dtype=torch.int32, device="cuda")
+        rew = torch.zeros((8, 2), device="cuda")
+        done = torch.zeros(8, dtype=torch.uint8, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        assert lib.evg_reset(None, None, None, None) == -1
+        assert lib.evg_step(None, p(act), p(obs), p(rew), p(done), None, None, None, None) == -1
+        assert lib.evg_step(h, None, p(obs), p(rew), p(done), None, None, None, None) == -1 and b"required" in lib.evg_last_error()
+        assert lib.evg_step(h, p(act), p(obs), None, p(done), None, None, None, None) == -1
+        assert lib.evg_step(h, p(act), p(obs), p(rew), None, None, None, None, None) == -1
+        assert lib.evg_observe(h, None, None) == -1 and lib.evg_random_actions(h, None, None) == -1
+        assert lib.evg_fog_of_war(h, None, None, None) == -1 and lib.evg_sightings(h, None, None) == -1
+        assert lib.evg_scripted_actions(h, 99, 0, p(obs), p(act), None) == -1 and lib.evg_scripted_actions(h, 1, 2, p(obs), p(act), None) == -1
+        assert lib.evg_smart_state(h, 3, p(obs), p(obs), None) == -1
+        ms = C.c_float()
+        assert lib.evg_rollout_random(h, 0, 1, p(act), p(obs), p(rew), p(done), None, None, None, C.byref(ms), None) == -1
+        assert lib.evg_rollout_policies(h, 5, 1, 77, 0, p(act), p(obs), p(rew), p(done), None, None, None, None, None) == -1
+        assert lib.evg_rollout_policies(h, 5, 0, 1, 3, p(act), None, p(rew), p(done), None, None, None, None, None) == -1
+        assert lib.evg_seed_stock_entropy(h, None, None) == -1 and b"STOCK" in lib.evg_last_error()      # handle is in the keyed mode
+        assert lib.evg_get_stock_entropy(h, None) == -1 and lib.evg_set_stock_entropy(h, None) == -1
+        g = np.zeros((8, 2, 12, 8), np.int32)
+        assert lib.evg_set_state(h, g.ctypes.data_as(C.c_void_p), None, None, None) == -1
+        # out-of-domain state is refused as a whole (nothing is written)
+        env_state = np.zeros((8, 4), np.int32)
+        nodes, health = np.zeros((8, 11, 2), np.int32), np.zeros((8, 2, 100), np.float64)
+        assert lib.evg_set_state(h, g.ctypes.data_as(C.c_void_p), nodes.ctypes.data_as(C.c_void_p), health.ctypes.data_as(C.c_void_p),
+                                 env_state.ctypes.data_as(C.c_void_p)) == -1 and b"out-of-domain" in lib.evg_last_error()
+        # the handle still works after all of that
+        assert lib.evg_reset(h, None, p(obs), None) == 0 and lib.evg_random_actions(h, p(act), None) == 0
+        assert lib.evg_step(h, p(act), p(obs), p(rew), p(done), None, None, None, None) == 0
+        torch.cuda.synchronize()
+        assert float(obs[0, 0, 0]) == 1.0 and int(done.sum()) == 0
+    finally:
+        lib.evg_destroy(h)
+    lib.evg_destroy(None)                                             # a null handle is ignored
+    # the Python mirror validates caller tensors before their pointers reach a kernel
+    env = evg.EvergladesVecEnv(8, seed=1)
+    env.reset()
+    import torch
+    with pytest.raises(ValueError):
+        env.random_actions(out=torch.zeros((8, 2, 7, 2), dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        env.fog_of_war(out=torch.zeros((8, 2, 12), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        env.sightings(out=torch.zeros((8, 2, 12, 4), dtype=torch.int8))                    # host tensor
+    with pytest.raises(ValueError):
+        env.smart_state(0, obs=env.obs[:, :, ::1].transpose(0, 1))                          # wrong shape / strides
+    with pytest.raises(ValueError):
+        env.scripted_actions("swarm", 0, out=torch.zeros((8, 2, 7, 4), dtype=torch.int32, device="cuda")[..., ::2])   # strided view
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((7, 2, 7, 2), dtype=torch.int32, device="cuda"))
+    env.close()
+
+
+_SHARD_CHILD = r"""
+import json, os, sys
+rank, world, total, seed, steps, out_dir, root = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7]
+sys.path.insert(0, root)
+import numpy as np
+import torch
+import torch.distributed as dist
+import everglades_amd as evg
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+first, cnt = evg.shard_range(total, world, rank)
+env = evg.EvergladesVecEnv(cnt, device="cuda:0", seed=seed, env_id_base=first, auto_reset=True)
+env.reset()
+env.rollout_random(steps, turns_per_launch=150)
+sd = env.episode_stats_device()
+g = evg.gather_episode_results(sd["returns"], sd["length"], sd["winner"], total)     # the path's one collective
+s = env.get_state()
+np.savez(os.path.join(out_dir, "rank%d.npz" % rank), first=first, cnt=cnt, groups=s["groups"], nodes=s["nodes"], health=s["health"], env=s["env"],
+         obs=env.obs.cpu().numpy(), g_returns=g["returns"].cpu().numpy(), g_winner=g["winner"].cpu().numpy(), g_length=g["length"].cpu().numpy(),
+         wins=np.array(g["wins"]), totals=env.episode_stats()["totals"])
+env.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_hip_path_sharded_over_two_processes_equals_one_handle(evg, tmp_path):
+    """SURVEY 8(e) on the PRODUCT path: two freshly spawned processes (started before anything touched the GPU in them) each own a
+    HIP handle for their contiguous shard (env_id_base from shard_range) on GPU 0 and gather episode results with the path's one
+    collective (gloo here; RCCL needs one GPU per rank).  State, observations, gathered per-env results and win counts equal
+    those of ONE handle of the full size: results do not depend on the sharding."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    total, seed, steps, world = 5000, 4242, 320, 2                     # uneven shards of 2500 (not a multiple of 32 envs per wave)
+    script = tmp_path / "shard_child.py"
+    script.write_text(_SHARD_CHILD)
+    port = 29600 + os.getpid() % 300
+    envv = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(total), str(seed), str(steps), str(tmp_path), ROOT], env=envv)
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    one = evg.EvergladesVecEnv(total, seed=seed, auto_reset=True)
+    one.reset()
+    one.rollout_random(steps, turns_per_launch=150)
+    s, st = one.get_state(), one.episode_stats()
+    parts = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    assert [int(p["first"]) for p in parts] == [0, 2500] and sum(int(p["cnt"]) for p in parts) == total
+    for k in ("groups", "nodes", "health", "env"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), s[k]), k
+    assert np.array_equal(np.concatenate([p["obs"] for p in parts]), _np(one.obs))
+    for p in parts:                                                   # every rank holds the results of ALL envs, in global order
+        assert np.array_equal(p["g_winner"], st["winner"]) and np.array_equal(p["g_length"], st["length"])
+        assert np.allclose(p["g_returns"], st["returns"], rtol=0, atol=1e-6)
+        assert p["wins"].tolist() == [int((st["winner"] == k).sum()) for k in (0, 1, 2)] + [int((st["winner"] < 0).sum())]
+    assert np.array_equal(sum(p["totals"] for p in parts), st["totals"])
+    one.close()

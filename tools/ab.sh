@@ -1,16 +1,17 @@
 #!/bin/bash
-# A/B on ONE box: bench a baseline build (libevg_base.so, a copy of an earlier libevg.so) and the working build (libevg.so)
-# alternately, through bench.py's diagnostic --library switch.
-# usage (inside gpurun): bash tools/ab.sh [extra bench.py args]   -> gpurun_out/ab.txt
+# A/B on ONE box: bench several builds of the library alternately through bench.py's diagnostic --library switch.
+# usage (inside gpurun): LIBS="libevg_base.so libevg.so" bash tools/ab.sh [extra bench.py args]   -> gpurun_out/ab.txt
+# (libevg_base.so = a copy of an earlier libevg.so kept beside the working build)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
+LIBS=${LIBS:-"libevg_base.so libevg.so"}
 : > gpurun_out/ab.txt
 for rep in 1 2 3; do
-  for lib in libevg_base.so libevg.so; do
-    timeout -k 10 200 python bench.py --no-cpu-baseline --library $PWD/everglades-ai-wargame_amd/$lib "$@" 2>/dev/null | python -c "
+  for lib in $LIBS; do
+    timeout -k 10 200 python bench.py --no-cpu-baseline --library $PWD/everglades-ai-wargame_amd/$lib "$@" 2>gpurun_out/ab_err.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); o=d['config'].get('one_launch_per_turn') or {}
-print('$lib', 'persistent %.3f G  kernel %.2f us | per-turn %.3f G  kernel %.2f us' % (d['value']/1e9, d['roofline']['kernel_ms']*1e3, o.get('env_steps_per_s',0)/1e9, o.get('kernel_ms',0)*1e3))" >> gpurun_out/ab.txt || exit 1
+print('%-16s' % '$lib', 'persistent %.3f G  kernel %.2f us | per-turn %.3f G  kernel %.2f us' % (d['value']/1e9, d['roofline']['kernel_ms']*1e3, o.get('env_steps_per_s',0)/1e9, o.get('kernel_ms',0)*1e3))" >> gpurun_out/ab.txt || { tail -5 gpurun_out/ab_err.txt; exit 1; }
   done
 done
 cat gpurun_out/ab.txt

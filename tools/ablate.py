@@ -8,13 +8,14 @@ import torch
 import everglades_amd as evg
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+TPL = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # turns per launch (50 = persistent form)
 for abl in (0, 16, 2, 18, 4, 1, 17, 49, 0):
     env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=abl))
     env.reset()
-    env.rollout_random(60)
+    env.rollout_random(60, turns_per_launch=TPL)
     res = []
     for seg in range(3):
-        ms = env.rollout_random(50, time_kernel=True)[-1]
+        ms = env.rollout_random(50, time_kernel=True, turns_per_launch=TPL)[-1]
         res.append(ms * 1e3)
     torch.cuda.synchronize()
     print("ablate=%2d  step kernel us at turns 61-110 / 111-160(reset at 150) / 161-210: %s" % (abl, ["%.1f" % r for r in res]), flush=True)

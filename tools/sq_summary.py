@@ -17,7 +17,7 @@ out = {"kernel_source_hash": kernel_source_hash(), "envs": ENVS, "workload": WOR
                "turns of the dispatch.", "kernels": {}}
 for form, (tail, tpl, nwin) in FORMS.items():
     mean, meta = {}, None
-    for d in sorted(glob.glob(os.path.join(P, form + "_p*"))):
+    for d in sorted(x for x in glob.glob(os.path.join(P, form + "_p*")) if os.path.isdir(x)):
         rows, m = counter_rows(d, form)
         rows = timed_window(rows, form)
         meta = m[-1]
