@@ -8,10 +8,11 @@ players of every env (the input generator, agents/State_Machine/random_actions.p
 env-step kernel (game_turn + observations + rewards, auto-reset on).  Inputs and outputs stay in HBM.
 
 Window.  Before anything is timed (and whatever --warmup says) the batch is brought to a DESYNCHRONISED
-steady state: during a 150-turn pre-roll env e is restarted at pre-roll turn e mod 150, so afterwards the
-episode phases of the batch are spread uniformly over 0..149 and every timed turn sees the episode-average
-mix of early (few fights) and late (many fights) positions, with ~1/150 of the envs resetting per turn.
-A K-step timed window of any length therefore measures the same thing.
+steady state: during a 150-turn pre-roll env e is restarted at pre-roll turn phase(e) = hash(e) mod 150
+(a multiplicative hash of the global env id, so neighbouring envs get unrelated phases), so afterwards the
+episode phases of the batch -- and of the 32 envs of every wavefront -- are spread uniformly over 0..149 and
+every timed turn sees the episode-average mix of early (few fights) and late (many fights) positions, with
+~1/150 of the envs resetting per turn.  A K-step timed window of any length therefore measures the same thing.
 
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); environments shard by
 contiguous global id (weak scaling: 65 536 per GPU) and the only collective is the gather of episode
@@ -87,13 +88,19 @@ def committed_counters(kind, n_local, workload, obs_dtype):
     return None
 
 
+def episode_phase(ids):
+    """phase(e) in 0..149 of global env id e (numpy or torch int64 array): Knuth's multiplicative hash, so that the envs of one
+    wavefront (32 consecutive ids) get unrelated phases"""
+    return (((ids * 2654435761) & 0xFFFFFFFF) >> 8) % PHASES
+
+
 def desynchronise(env, first_id, workload, rollout):
-    """150 turns, one launch per turn; after turn j the envs with global id = j (mod 150) start a new episode."""
+    """150 turns, one launch per turn; after turn j the envs with phase(global id) = j start a new episode."""
     import torch
-    ids = torch.arange(first_id, first_id + env.num_envs, device=env.device, dtype=torch.int64)
+    phase = episode_phase(torch.arange(first_id, first_id + env.num_envs, device=env.device, dtype=torch.int64))
     for j in range(PHASES):
         rollout(1, False, 1)
-        env.reset(mask=((ids % PHASES) == j).to(torch.uint8))
+        env.reset(mask=(phase == j).to(torch.uint8))
 
 
 def cpu_parity(seed, n, steps_after_preroll, gpu_stats, gpu_state):
@@ -107,10 +114,10 @@ def cpu_parity(seed, n, steps_after_preroll, gpu_stats, gpu_state):
     om.lib().evo_set_num_threads(usable_cores())
     o = om.Oracle(n, seed=seed, auto_reset=True)
     o.reset()
-    ids = np.arange(n)
+    phase = episode_phase(np.arange(n, dtype=np.int64))
     for j in range(PHASES):
         o.step_noobs(o.random_actions())
-        o.reset(mask=(ids % PHASES == j).astype(np.uint8))
+        o.reset(mask=(phase == j).astype(np.uint8))
     for _ in range(steps_after_preroll):
         o.step_noobs(o.random_actions())
     st = o.episode_stats()
@@ -237,16 +244,20 @@ def main():
     env, rollout = make_env(args.obs_dtype)
     stats_dev = env.episode_stats_device()
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
-    evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)   # first use loads torch's small kernels / opens the RCCL channels
+    if world > 1:      # first use opens the RCCL channels and loads torch's small kernels: not part of the timed region
+        evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch)
         played += args.warmup
 
-    # ---- timed region: exactly K steps, the gather of episode results included
+    # ---- timed region: exactly K steps; with more than one rank the path's one collective (the gather of episode results) is
+    # inside it (a single rank has nothing to exchange: its results are already where rank 0 reads them)
     barrier()
     t0 = time.perf_counter()
     kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch)
-    gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
+    gathered = None
+    if world > 1:
+        gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
     barrier()
     dt_local = time.perf_counter() - t0
     played += args.steps
@@ -261,6 +272,8 @@ def main():
         dt = max(p["seconds"] for p in per_rank)
     step_kernel_ms = kernel_ms_sum / args.steps
     st = env.episode_stats()
+    if gathered is None:
+        gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
     final_state = env.get_state() if (world == 1 and not args.no_cpu_baseline and args.workload == "random" and played <= 2000) else None
 
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
@@ -338,7 +351,7 @@ def main():
                                     "step kernel, orders written to an [N,2,7,2] tensor; persistent rollout form, see turns_per_launch), auto-reset, obs %s [N,2,105]" if args.workload == "random" else
                                     "%d concurrent DemoMap games per GPU, on-device Cycle_BRush_Turn25 vs SwarmAgent (BASELINE config 5; both bots fused into the "
                                     "step kernel, orders written out; episodes end by BaseCapture after 84-94 turns), auto-reset, obs %s [N,2,105]") % (n_local, args.obs_dtype),
-                       "window": "desynchronised steady state: 150-turn pre-roll restarts env e at pre-roll turn e mod 150 (episode phases uniform over 0..149), "
+                       "window": "desynchronised steady state: 150-turn pre-roll restarts env e at pre-roll turn hash(e) mod 150 (episode phases uniform over 0..149, unrelated between neighbouring envs), "
                                  "then 150 settle turns, --warmup turns and the K timed turns",
                        "envs_per_gpu": n_local, "total_envs": total, "turns_per_launch": tpl, "turns_of_last_timed_launch": turns_last_launch,
                        "one_launch_per_turn": per_turn_launch, "obs_float64": obs_f64, "parallelism": "env-sharded x%d" % world,

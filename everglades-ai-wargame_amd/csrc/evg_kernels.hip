@@ -361,10 +361,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     STAMP(0);
     STAMP_WAVE_BEGIN();
-#ifdef EVG_DIAG
-    const int kStaggerSleeps = (A->io_.ablate >> 8) & 0xFFu ? (int)((A->io_.ablate >> 8) & 0xFFu) - 1 : 20;   // experiment knob (tools/stagger.py): n - 1 x 256 cycles
+#ifdef EVG_DIAG      // experiment knobs (tools/stagger.py): delay = slot x a + simd x b sleeps of 256 cycles, a = ablate[15:8] - 1, b = ablate[23:16]
+    const int kStaggerSlot = (A->io_.ablate >> 8) & 0xFFu ? (int)((A->io_.ablate >> 8) & 0xFFu) - 1 : 20, kStaggerSimd = (int)((A->io_.ablate >> 16) & 0xFFu);
 #else
-    constexpr int kStaggerSleeps = 20;                      // x 256 cycles (s_sleep 4)
+    constexpr int kStaggerSlot = 20, kStaggerSimd = 0;      // x 256 cycles (s_sleep 4)
 #endif
     // ---- prologue loads: the constant tables (one blob, already in its LDS layout) and this lane's state (env fastest; the two player rows of a group index interleave
     // across lanes).  Every load is issued before the first LDS store, so the launch pays ONE memory round trip here
@@ -402,8 +402,11 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // Single-turn launches: all 2 048 wavefronts start together and every SIMD's two waves would run the same phases in
         // lockstep, competing for the same issue slots phase by phase.  The wave in hardware slot 1 therefore waits STAGGER
         // cycles here, with its loads already in flight (tools/stagger.py: 35.0 -> 32.6 us per launch at 65 536 envs) ...
-        if (__builtin_amdgcn_s_getreg(6148) & 1u)            // HW_ID.wave_id: the wave's slot on its SIMD
-            for (int i = 0; i < kStaggerSleeps; ++i) __builtin_amdgcn_s_sleep(4);
+        {
+            const uint32_t hw = __builtin_amdgcn_s_getreg(12292);                  // HW_ID[6:0]: wave_id (the wave's slot on its SIMD) [3:0], simd_id [5:4]
+            const int nsleep = (int)(hw & 1u) * kStaggerSlot + (int)((hw >> 4) & 3u) * kStaggerSimd;
+            for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(4);
+        }
         // ... and the orders this kernel draws itself need only the turn and the episode (the first two loads), so they are
         // drawn while the group / node words are still on their way
         if (io.gen_actions == 1) gen_random_rows(S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, turn, P, act_in);

@@ -75,8 +75,11 @@ enum { EVG_RES_DEFENSE = 1, EVG_RES_OBSERVE = 2 };
  * config/UnitDefinitions.json plus the army of everglades_env.py:145-156.  Node arrays are
  * indexed by node ID (1..11; entry 0 unused).  Domain checked by evg_create:
  *   distances 0 (not connected) or 1..7; control_points 1..511; defense >= 0;
- *   unit damage/speed/control/cost >= 1 and small (<= 15), unit health >= 1;
- *   group sizes even, 2..12, summing to <= 100 per player.
+ *   unit damage/speed/control/cost 1..15, unit health 1..255, at most 4 unit types;
+ *   the army SHAPE is the reference's hard-coded one (everglades_env.py:145-156): group_size must be 8 for groups 0..10 and
+ *   12 for group 11 of both players -- anything else is refused with EVG_ERR_INVALID (the unit TYPE of every group is free);
+ *   total damage of an army (sum of size x unit damage) <= 255; max_turns 1..255;
+ *   global env ids are 32-bit keys of the random streams: env_id_base + num_envs <= 2^32.
  */
 typedef struct evg_tables {
     int32_t node_dist[EVG_NUM_NODES + 1][EVG_NUM_NODES + 1];

@@ -6,17 +6,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import everglades_amd as evg
 N = 65536
-for stg in (1, 9, 17, 21, 25, 33, 1):        # knob value n = n - 1 sleeps of 256 cycles (0 = the product default)
-    env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=stg << 8))
+for a, b, h in ((21, 0, 0), (1, 0, 0), (13, 0, 0), (29, 0, 0), (21, 0, 0)):   # delay = slot x (a - 1) + simd x b sleeps of 256 cycles
+    env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=(a << 8) | (b << 16)))
     env.reset()
     ids = torch.arange(N, device=env.device)
     for j in range(150):
         env.rollout_random(1)
-        env.reset(mask=((ids % 150) == j).to(torch.uint8))
+        env.reset(mask=((((ids * 2654435761) & 0xFFFFFFFF) >> 8) % 150 == j).to(torch.uint8))
     env.rollout_random(150)
     res = [env.rollout_random(160, time_kernel=True)[-1] * 1e3 for _ in range(3)]
     torch.cuda.synchronize()
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record(); env.rollout_random(300); t1.record(); torch.cuda.synchronize()
-    print("stagger %2d - 1 x 256 cycles: step kernel %s us per launch; 300 launches back to back: %.2f us per turn" % (stg, ["%.2f" % r for r in res], t0.elapsed_time(t1) / 300 * 1e3), flush=True)
+    print("stagger slot x (%2d - 1) + simd x %2d (x 256 cycles): step kernel %s us per launch; 300 launches back to back: %.2f us per turn" % (a, b, ["%.2f" % r for r in res], t0.elapsed_time(t1) / 300 * 1e3), flush=True)
     env.close()

@@ -17,8 +17,12 @@ env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True, library=evg._lib.STAMPS_L
 env.reset()
 L = env.L
 L.evg_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
+ids = torch.arange(N, device=env.device)
+for j in range(150):                      # desynchronise the episodes like bench.py does
+    env.rollout_random(1)
+    env.reset(mask=((((ids * 2654435761) & 0xFFFFFFFF) >> 8) % 150 == j).to(torch.uint8))
 env.rollout_random(150, turns_per_launch=150)
-for rep in range(2):
+for rep in range(3):
     ms = env.rollout_random(TURNS, turns_per_launch=TURNS, time_kernel=True)[-1] * TURNS
     st = np.zeros(((N + 15) // 16, 16), np.uint64)
     assert L.evg_debug_read_stamps(env._h, st.ctypes.data_as(C.c_void_p)) == 0
@@ -33,6 +37,7 @@ for rep in range(2):
     wave_id, simd, pipe, cu, sh, se = hw & 15, (hw >> 4) & 3, (hw >> 6) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
     print("launch of %d turns: HIP-event time %.1f us; per-wave duration mean %.1f  min %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us; last start %.1f us, last end %.1f us"
           % (TURNS, ms * 1e3, dur.mean(), dur.min(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), dur.max(), start.max(), end.max()))
+    print("   wave END times: p10 %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us" % tuple(np.percentile(end, q) for q in (10, 50, 90, 99, 100)))
     print("   by XCD: " + "  ".join("%d: n=%d mean %.0f max %.0f" % (x, (xcc == x).sum(), dur[xcc == x].mean(), dur[xcc == x].max()) for x in sorted(set(xcc))))
     key = (xcc * 8 + se) * 64 + sh * 32 + cu * 2 + 0
     simd_key = key * 4 + simd
