@@ -61,9 +61,8 @@ namespace evg {
 // Phase markers (stamps build only).  Tried and rejected here: alternating s_setprio between the two wavefronts that share a
 // SIMD.  With equal priority the arbiter favours the older wave (hardware slot 0 finishes a 150-turn launch after 2.31 ms,
 // its partner after 3.04 ms, profiles/r02_c_wave_times.txt); flipping priorities per phase or per turn narrows that gap but
-// leaves the END of the slower wave where it was (3.14 vs 3.14-3.20 ms, profiles/r02_d_wave_times_priority_schemes.txt): the
-// pair's instruction issue is what is saturated (one wave64 VALU instruction per 4 cycles per SIMD), so only fewer
-// instructions make the launch shorter.
+// leaves the END of the slower wave where it was (3.14 vs 3.14-3.20 ms, profiles/r02_d_wave_times_priority_schemes.txt): what
+// the pair can issue together is conserved, so only fewer instructions (and fewer waits) per turn make the launch shorter.
 #define PHASE(i) STAMP(i)
 
 // LPW = lanes of the wavefront that own an env side (lane = 2 * env_slot + player): 64 (32 envs per wave) or 32
@@ -95,18 +94,12 @@ struct __align__(16) StepLds {
 // issue order (so do the vector-memory units, per address), so a boundary needs neither s_barrier nor a wait for outstanding
 // global loads/stores (what __syncthreads() would add: s_waitcnt vmcnt(0) stalls every phase behind the turn's
 // observation and health stores): it only has to keep the COMPILER from moving memory accesses across it.
-#if defined(EVG_EXP_SYNC) && EVG_EXP_SYNC == 1          /* experiment builds only (tools/ab.sh) */
-#define WAVE_SYNC() __syncthreads()
-#elif defined(EVG_EXP_SYNC) && EVG_EXP_SYNC == 2
-#define WAVE_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
-#else
 #define WAVE_SYNC()                                            \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
         asm volatile("" ::: "memory");                         \
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
-#endif
 
 // 12-input sorting network (tools/gen_sort12.py: 42 compare-exchanges, verified with the 0-1 principle)
 #define EVG_SORT12_CES(CE) \
