@@ -58,11 +58,7 @@ namespace evg {
 #define STAMP_WAVE_END()
 #endif
 
-// Phase markers (stamps build only).  Tried and rejected here: alternating s_setprio between the two wavefronts that share a
-// SIMD.  With equal priority the arbiter favours the older wave (hardware slot 0 finishes a 150-turn launch after 2.31 ms,
-// its partner after 3.04 ms, profiles/r02_c_wave_times.txt); flipping priorities per phase or per turn narrows that gap but
-// leaves the END of the slower wave where it was (3.14 vs 3.14-3.20 ms, profiles/r02_d_wave_times_priority_schemes.txt): what
-// the pair can issue together is conserved, so only fewer instructions (and fewer waits) per turn make the launch shorter.
+// Phase markers (stamps build only).
 #define PHASE(i) STAMP(i)
 
 // LPW = lanes of the wavefront that own an env side (lane = 2 * env_slot + player): 64 (32 envs per wave) or 32
@@ -399,6 +395,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const uint32_t hw = __builtin_amdgcn_s_getreg(12292);                  // HW_ID[6:0]: wave_id (the wave's slot on its SIMD) [3:0], simd_id [5:4]
             const int nsleep = (int)(hw & 1u) * kStaggerSlot + (int)((hw >> 4) & 3u) * kStaggerSimd;
             for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(4);
+            // (issue priority for either wave of the pair makes a single-turn launch no shorter: for the late wave 32.5 -> 38.0 us,
+            // for the early wave no change; A/B on one box)
         }
         // ... and the orders this kernel draws itself need only the turn and the episode (the first two loads), so they are
         // drawn while the group / node words are still on their way
@@ -436,6 +434,13 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int lane_ = threadIdx.x;
     if (MULTI) { asm volatile("" : "+s"(A)); asm volatile("" : "+v"(lane_)); T = S.T; }
     const int lane = lane_;
+    if constexpr (MULTI) {
+        // The two waves of a SIMD take turns in issue priority, one turn each (hardware wave slot + turn parity): with equal
+        // priority the arbiter favours the older wave throughout, it finishes a 150-turn launch 25 % earlier and its partner then
+        // runs alone, which uses the SIMD less well than two waves do (profiles/r02_c_wave_times.txt, r02_d_*).
+        // Measured: 17.9 -> 17.2 us per turn (A/B on one box).
+        if ((__builtin_amdgcn_s_getreg(6148) + (uint32_t)iter) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
     if (MULTI) PHASE(0);                                // diagnostic build: the stamps of a launch are those of its last turn
     const bool envlane = LPW == WG || lane < LPW;
     const int E = envlane ? lane >> 1 : 0, P = lane & 1;
