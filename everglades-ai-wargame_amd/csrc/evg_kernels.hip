@@ -393,7 +393,9 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // cycles here, with its loads already in flight (tools/stagger.py: 35.0 -> 32.6 us per launch at 65 536 envs) ...
         {
             const uint32_t hw = __builtin_amdgcn_s_getreg(12292);                  // HW_ID[6:0]: wave_id (the wave's slot on its SIMD) [3:0], simd_id [5:4]
-            const int nsleep = (int)(hw & 1u) * kStaggerSlot + (int)((hw >> 4) & 3u) * kStaggerSimd;
+            // (only while the whole grid is resident at once, i.e. up to 2 048 workgroups = 65 536 envs: a larger grid queues
+            // behind itself and its waves start at different times anyway)
+            const int nsleep = gridDim.x <= 2048u ? (int)(hw & 1u) * kStaggerSlot + (int)((hw >> 4) & 3u) * kStaggerSimd : 0;
             for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(4);
             // (issue priority for either wave of the pair makes a single-turn launch no shorter: for the late wave 32.5 -> 38.0 us,
             // for the early wave no change; A/B on one box)
