@@ -216,3 +216,38 @@ def test_create_rejects_bad_arguments_before_touching_a_device(evg):
     assert create(env_id_base=2 ** 40)[0] == -1
     assert create(env_id_base=2 ** 32 - 4)[0] in (0, -2)          # fits exactly: accepted (or no device here)
     assert lib.evg_create(None, None) == -1
+
+
+def test_bench_window_helpers():
+    """bench.py's desynchronising pre-roll: the episode phase of a global env id is the same function on the device (torch) and
+    in the CPU replay (numpy), covers 0..149 about uniformly and is unrelated between neighbouring envs; the hash that ties
+    committed counter passes to a build depends on the kernel sources only."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("evg_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ids = np.arange(70000, 70000 + 65536, dtype=np.int64)
+    ph = bench.episode_phase(ids)
+    assert np.array_equal(ph, bench.episode_phase(torch.arange(70000, 70000 + 65536, dtype=torch.int64)).numpy())
+    assert ph.min() == 0 and ph.max() == bench.PHASES - 1
+    cnt = np.bincount(ph, minlength=bench.PHASES)
+    assert cnt.min() > 0.8 * 65536 / bench.PHASES and cnt.max() < 1.2 * 65536 / bench.PHASES
+    per_wave = ph.reshape(-1, 32)                                   # the 32 envs of a wavefront: a spread of phases, not a window
+    assert (per_wave.max(axis=1) - per_wave.min(axis=1) > 75).mean() > 0.99
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    sys_path_tools = os.path.join(ROOT, "tools")
+    spec2 = importlib.util.spec_from_file_location("evg_prof", os.path.join(sys_path_tools, "_prof.py"))
+    prof = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(prof)
+    assert prof.kernel_source_hash() == h                           # the profile summaries are keyed by the same hash
+    for kind in ("pmc_traffic", "sq_counters"):                     # whatever is committed for THIS build parses and has what bench.py reads
+        d = bench.committed_counters(kind, 65536, "random", "float32")
+        if d is not None:
+            if kind == "pmc_traffic":
+                for form in ("persistent", "one_launch_per_turn"):
+                    f = d["forms"][form]
+                    assert 971 <= f["bytes_per_env_step_steady"] < 4530 and f["state_round_trip_bytes_per_env"] in (0, 320)
+            else:
+                assert 1000 < d["kernels"]["persistent"]["valu_insts_per_wave_turn"] < 10000
