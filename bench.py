@@ -39,7 +39,8 @@ SURVEY_ALGO_BYTES_PER_ENV_STEP = 4530
 # that were hit (64 B read + 64 B written per group row, 96 for group 11) -- see DESIGN.md section 3.
 MANDATORY_OUTPUT_BYTES = {"float32": 971, "float64": 971 + 840, "int16": 971 - 420}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMD-32, one wave64 VALU instruction per 2 cycles, 2.4 GHz
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0   # 1024 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes per cycle: what the
+                                                     # 78.6 TFLOP/s non-packed FP32 / FP64 vector peak amounts to; SQ_ACTIVE_INST_VALU agrees), 2.4 GHz
 PHASES = 150                 # episode length of random vs random (server.py:321): the pre-roll spreads phases over it
 
 
@@ -185,6 +186,7 @@ def main():
                     help="random: BASELINE metric config (random vs random); scripted: BASELINE config 5 (cycle_rush_turn25 vs swarm)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
+    ap.add_argument("--diag-lanes", type=int, default=0, help="diagnostics only: kernel variant of libevg_diag.so (evg_diag_configure lanes)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -226,7 +228,8 @@ def main():
 
     def make_env(obs_dtype):
         """A handle in the desynchronised steady state + its rollout function (nsteps, timed, turns per launch) -> kernel ms sum."""
-        env = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed, env_id_base=first, obs_dtype=obs_dtype, auto_reset=True, library=args.library)
+        env = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed, env_id_base=first, obs_dtype=obs_dtype, auto_reset=True, library=args.library,
+                                   diag=dict(lanes=args.diag_lanes) if args.diag_lanes else None)
         env.reset()
 
         def rollout(nsteps, timed, tpl):
@@ -341,7 +344,7 @@ def main():
             ach = insts / (step_kernel_ms * 1e-3)
             valu = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s", "frac": ach / VALU_PEAK_WAVE_INSTS_PER_S,
                     "valu_insts_per_wave_turn": k["valu_insts_per_wave_turn"], "wave_cycles_per_wave_turn": k.get("wave_cycles_per_wave_turn"),
-                    "source": sq["_file"], "peak_is": "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}
+                    "source": sq["_file"], "peak_is": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
         out = {
             "metric": "env-steps/sec at 65536 concurrent DemoMap games, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1165,6 +1165,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     STAMP_WAVE_END();
 }
 
+#ifdef EVG_DIAG
+#include "evg_step4.inc"      // the four-lanes-per-env mapping: correct, measured slower; diagnostic library only
+#endif
+
 #undef S
 #undef io
 
@@ -1397,6 +1401,21 @@ static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtyp
     return (int)hipGetLastError();
 }
 
+#ifdef EVG_DIAG
+template <bool MULTI>
+static int launch_step4(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
+    const dim3 grid((S.N + 15) / 16), block(WG);
+    const StepArgs args{S, io};
+    switch (obs_dtype) {
+        case EVG_OBS_F32: hipLaunchKernelGGL((evg_step4_kernel<float, MULTI>), grid, block, 0, s, args); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL((evg_step4_kernel<double, MULTI>), grid, block, 0, s, args); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL((evg_step4_kernel<int16_t, MULTI>), grid, block, 0, s, args); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+#endif
+
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool multi = io.turns > 1;
@@ -1413,6 +1432,7 @@ int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream
         return (int)hipGetLastError();
     }
 #ifdef EVG_DIAG
+    if (io.lanes_per_wave == 4 && !S.mt_key) return multi ? launch_step4<true>(S, io, obs_dtype, s) : launch_step4<false>(S, io, obs_dtype, s);
     if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
 #endif
     return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);

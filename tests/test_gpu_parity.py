@@ -1051,3 +1051,51 @@ def test_hip_path_sharded_over_two_processes_equals_one_handle(evg, tmp_path):
         assert p["wins"].tolist() == [int((st["winner"] == k).sum()) for k in (0, 1, 2)] + [int((st["winner"] < 0).sum())]
     assert np.array_equal(sum(p["totals"] for p in parts), st["totals"])
     one.close()
+
+
+def test_four_lanes_per_env_variant_matches_oracle(evg, oracle_mod):
+    """The four-lanes-per-env mapping of the step kernel (csrc/evg_step4.inc: 16 envs per wavefront, a side shared by two lanes)
+    was built and measured slower; it lives in the diagnostic library and must give the same results:
+    caller-supplied orders incl. negative / aliased / duplicate ids, fused random and scripted rollouts in both launch forms,
+    a partial last workgroup."""
+    from gen_policies import policy_actions
+    D = dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=4))
+    N, seed = 333, 31
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **D)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    obs = _np(env.reset()).astype(np.float64)
+    assert np.array_equal(obs, ora.reset())
+    rng = np.random.default_rng(5)
+    for t in range(190):
+        a = policy_actions("wild" if t % 3 else "brawl", obs, t, rng) if t < 120 else _np(env.random_actions()).copy()
+        o, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(a)
+        obs = _np(o).astype(np.float64)
+        assert np.array_equal(obs, o_obs), ("obs", t)
+        assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(done), o_done)
+        assert np.allclose(_np(rew), o_rew, rtol=0, atol=REWARD_ATOL)
+    check_state(env, ora.get_state(), "stepwise")
+    for tpl in (1, 150):
+        env.rollout_random(170, turns_per_launch=tpl)
+        for t in range(170):
+            a = ora.random_actions()
+            o_obs, _, _, _ = ora.step(a)
+        assert np.array_equal(_np(env.obs).astype(np.float64), o_obs) and np.array_equal(_np(env._actions), a), tpl
+        check_state(env, ora.get_state(), ("rollout", tpl))
+    assert np.array_equal(env.episode_stats()["totals"], ora.episode_stats()["totals"])
+    env.close()
+    seats = ("cycle_target_node11P2", "swarm")
+    pid = [evg.EvergladesVecEnv.POLICIES[s] for s in seats]
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **D)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset()
+    o_obs = ora.reset()
+    env.rollout_policies(230, seats[0], seats[1], fused=True, turns_per_launch=150)
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(230):
+        ora.scripted_actions(pid[0], 0, o_obs, oa)
+        ora.scripted_actions(pid[1], 1, o_obs, oa)
+        o_obs, _, _, _ = ora.step(oa)
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs)
+    check_state(env, ora.get_state(), "scripted")
+    env.close()

@@ -16,7 +16,10 @@ def kernel_source_hash():
 
 
 def step_kernel(name, form, dtype="float"):
-    return "evg_step_kernel<%s, 64, %s" % (dtype, FORMS[form][0]) in name
+    """the step kernel of a launch form: the two-lane kernel evg_step_kernel<OT, 64, MULTI, false> or the four-lane kernel
+    evg_step4_kernel<OT, MULTI>, whichever the run used"""
+    multi = FORMS[form][0].split(",")[0]
+    return "evg_step_kernel<%s, 64, %s" % (dtype, FORMS[form][0]) in name or "evg_step4_kernel<%s, %s>" % (dtype, multi) in name
 
 
 def counter_rows(directory, form):
