@@ -67,7 +67,8 @@ def kernel_source_hash():
     """Identifies the kernel sources the running libevg.so was built from (build() rebuilds it from them): the committed
     counter passes under profiles/ carry the same hash, and figures from another build are not used."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "evg.h")]):
+    csrc = os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc")      # the files the product kernels are compiled from
+    for f in [os.path.join(csrc, n) for n in ("evg_device.h", "evg_kernels.hip", "evg_mt.h", "evg_rng.h")] + [os.path.join(ROOT, "include", "evg.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

@@ -350,7 +350,8 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(EVG_ERR_NO_DEVICE, "device %d is %s; libevg is built for gfx950 (MI355X) only", cfg->device_id, prop.gcnArchName);
-    HIP_TRY(hipSetDevice(cfg->device_id));
+    DeviceGuard guard(cfg->device_id);              // the caller's current device is restored on every way out
+    if (guard.err != hipSuccess) return fail(EVG_ERR_HIP, "selecting device %d failed: %s", cfg->device_id, hipGetErrorString(guard.err));
 
     evg_handle* h = new evg_handle();
     h->cfg = *cfg;
@@ -415,7 +416,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
 
 void evg_destroy(evg_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->cfg.device_id);
+    DeviceGuard guard(h->cfg.device_id);
     for (void* p : h->allocs) (void)hipFree(p);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     delete h;
