@@ -194,13 +194,15 @@ static void fill_lds_tables(DevTables* D) {
     memset(&L, 0, sizeof(L));
     for (int n = 0; n < 12; ++n) {
         L.adj[n] = D->adj_row[n];
-        L.cp[n] = D->control_points[n]; L.ts[n] = D->team_start[n]; L.res[n] = D->resource[n];
+        L.cp[n] = D->control_points[n]; L.ts[n] = D->team_start[n]; L.res[n] = ((D->resource[n] & EVG_RES_DEFENSE) ? 1 : 0) | ((D->resource[n] & EVG_RES_OBSERVE) ? 1 << 16 : 0);
         L.init_node[n] = D->init_node[n];
     }
     for (int i = 0; i < 48; ++i) { L.den[i] = (&D->den_tab[0][0])[i]; L.rcp[i] = (&D->rcp_tab[0][0])[i]; }
     for (int i = 0; i < 24; ++i) L.init_grp[i] = D->init_grp[i];
     L.nib[0] = D->p1map_nib;
     for (int p = 0; p < NP; ++p) { L.nib[1 + p] = D->speed_nib[p]; L.nib[3 + p] = D->control_nib[p]; L.nib[5 + p] = D->cost_nib[p]; L.nib[7 + p] = D->type_nib[p]; }
+    L.nib[10] = D->p1inv_nib;
+    L.nib[11] = 0;
     L.nib[9] = (uint64_t)(uint32_t)D->max_turns | ((uint64_t)(D->damage_nib & 0xFFFFu) << 8) | ((uint64_t)(D->fast_div ? 1u : 0u) << 24);
 }
 

@@ -42,9 +42,11 @@ constexpr uint32_t MODE_IDLE = 0, MODE_READY = 1, MODE_MOVING = 2;
 struct __attribute__((aligned(16))) LdsTables {
     uint64_t adj[12];            // nibble j of row i = distance i -> j (0 = not connected)
     double   den[48], rcp[48];   // DevTables::den_tab / rcp_tab flattened [type][node]
-    int32_t  cp[12], ts[12], res[12];       // control points, team start, resource bits by node ID
+    int32_t  cp[12], ts[12], res[12];       // control points, team start by node ID; res = the two board flags as the observation
+                                            // shows them: (DEFENSE ? 1 : 0) | (OBSERVE ? 1 : 0) << 16 (server.py:442-443)
     uint32_t init_grp[24], init_node[12];   // state right after game_init (auto-reset inside the kernel)
-    uint64_t nib[10];            // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24
+    uint64_t nib[12];            // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24;
+                                 // [10] = p1inv (nibble n = slot of player 1's board view that shows node n); [11] unused
 };
 static_assert(sizeof(LdsTables) % 16 == 0, "the kernel copies the blob in 16-byte pieces");
 

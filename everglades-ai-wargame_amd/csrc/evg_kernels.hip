@@ -565,6 +565,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     const uint32_t contested = (play && !ABLATED(2u)) ? (occ & (uint32_t)xchg1((int)occ)) : 0u;
     if (__any(contested != 0)) {                          // wave-uniform: skip when none of the 32 envs fights
+        if (envlane) {
+#pragma unroll
+            for (int n = 0; n < 12; ++n) L.u.c.FS[n][lane] = 0;
+        }
         uint32_t key[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
@@ -577,21 +581,25 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define EVG_CE(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }
         EVG_SORT12_CES(EVG_CE)
 #undef EVG_CE
-        uint32_t a0 = 0, a1 = 0, a2 = 0, fmask = 0;
+        // List order (server.py:549-566 walks node.groups[p]): the prefix `base` of alive fighting units listed before a group at its
+        // node comes from one returning LDS add per group into this side's per-node total (the FS column of the lane, high half;
+        // the low half receives the damage-pool offset in stage 1): the LDS executes a wavefront's adds in issue order.
+        uint32_t fmask = 0, basev[12];
+        bool fightv[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {                // list order
+        for (int i = 0; i < 12; ++i) {
             const uint32_t kk = key[i];
-            const uint32_t gid = (kk >> 17) & 15u, loc = (kk >> 13) & 15u, mask = (kk >> 1) & 0xFFFu;
-            const bool fights = (kk & 1u) && ((contested >> loc) & 1u);
-            const uint32_t idx = loc >> 2, sh = (loc & 3u) * 8;
-            const uint32_t cur = idx == 0 ? a0 : (idx == 1 ? a1 : a2);
-            const uint32_t base = (cur >> sh) & 0xFFu;
-            const uint32_t add = fights ? (uint32_t)__popc(mask) << sh : 0u;
-            a0 += idx == 0 ? add : 0u;
-            a1 += idx == 1 ? add : 0u;
-            a2 += idx == 2 ? add : 0u;
-            fmask |= (fights ? 1u : 0u) << gid;
-            if (envlane) L.u.c.SNAP[gid][lane] = fights ? (0x80000000u | (base << 16) | (loc << 12) | mask) : 0u;
+            const uint32_t loc = (kk >> 13) & 15u, mask = (kk >> 1) & 0xFFFu;
+            fightv[i] = (kk & 1u) && ((contested >> loc) & 1u);
+            basev[i] = envlane ? atomicAdd(&L.u.c.FS[loc][lane], fightv[i] ? (uint32_t)__popc(mask) << 16 : 0u) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const uint32_t kk = key[i];
+            const uint32_t gid = (kk >> 17) & 15u;
+            fmask |= (fightv[i] ? 1u : 0u) << gid;
+            // fights | prefix << 16 | node << 12 | alive mask: bits 16..1 of the key are already node << 12 | mask
+            if (envlane) L.u.c.SNAP[gid][lane] = fightv[i] ? (0x80000000u | basev[i] | ((kk >> 1) & 0xFFFFu)) : 0u;
         }
         if (envlane) { L.u.c.TURN[lane] = (uint32_t)turn; L.u.c.EPI[lane] = episode; }
         // damage bytes this side needs: one per alive fighting unit, rounded up to a word per node
@@ -601,8 +609,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             while (c) {
                 const uint32_t n = (uint32_t)__ffs(c) - 1u;
                 c &= c - 1;
-                const uint32_t aw = (n >> 2) == 0 ? a0 : ((n >> 2) == 1 ? a1 : a2);
-                ndw += (int)((((aw >> ((n & 3u) * 8)) & 0xFFu) + 3u) >> 2);
+                ndw += (int)(((L.u.c.FS[n][col] >> 16) + 3u) >> 2);
             }
         }
         PHASE(3);
@@ -649,10 +656,9 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 while (c) {
                     const uint32_t n = (uint32_t)__ffs(c) - 1u;
                     c &= c - 1;
-                    const uint32_t aw = (n >> 2) == 0 ? a0 : ((n >> 2) == 1 ? a1 : a2);
-                    const uint32_t tn = (aw >> ((n & 3u) * 8)) & 0xFFu;
-                    L.u.c.FS[n][lane] = (tn << 16) | (uint32_t)doff;
-                    doff += (int)((tn + 3u) >> 2);
+                    const uint32_t tnw = L.u.c.FS[n][lane] & 0xFFFF0000u;     // alive fighting units of this side at the node (stage 0)
+                    L.u.c.FS[n][lane] = tnw | (uint32_t)doff;
+                    doff += (int)(((tnw >> 16) + 3u) >> 2);
                 }
             }
             for (int i = lane; i < ndwords; i += WG) L.u.c.DP[i] = 0;
@@ -855,19 +861,19 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int k = 0; k < 12; ++k) gw[k] = envlane ? L.G[k][col] : 0u;
     if (play && !ABLATED(4u)) {
+        static_assert(MODE_READY == 1 && MODE_MOVING == 2, "ready -> moving is +1 in the mode field; bit 1 of the field is `moving`");
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
             const uint32_t w = gw[k];
-            const uint32_t mode = (w & G_MODE_M) >> G_MODE_S;
             const bool alive = (w & G_MASK_M) != 0;                                    // not destroyed, :663
-            const int nd = (int)((w & G_DIST_M) >> G_DIST_S) - (int)((spd_n >> (4 * k)) & 15u);   // :671
-            const bool arrive = alive && mode == MODE_MOVING && nd <= 0;               // :678-695
-            const uint32_t w_ready = (w & ~G_MODE_M) | (MODE_MOVING << G_MODE_S);      // :664-667
+            const uint32_t spd = (uint32_t)((spd_n >> (4 * k)) & 15u) << G_DIST_S;     // the group's speed, aligned with the distance field
+            const bool ready = alive && (w & G_MODE_M) == (MODE_READY << G_MODE_S);
+            const bool moving = alive && (w & (MODE_MOVING << G_MODE_S)) != 0;
+            const bool arrive = moving && (w & G_DIST_M) <= spd;                       // :671, :678-695
             const uint32_t w_arrive = (w & ~(G_LOC_M | G_DEST_M | G_DIST_M | G_MODE_M)) | ((w & G_DEST_M) >> G_DEST_S);
-            const uint32_t w_transit = (w & ~G_DIST_M) | ((uint32_t)(nd & 7) << G_DIST_S);
-            uint32_t nw_ = w;
-            nw_ = (alive && mode == MODE_READY) ? w_ready : nw_;
-            nw_ = (alive && mode == MODE_MOVING) ? (arrive ? w_arrive : w_transit) : nw_;
+            uint32_t nw_ = ready ? w + (1u << G_MODE_S) : w;                           // :664-667: moves from the next turn on
+            nw_ = moving ? w - spd : nw_;                                              // in transit: distance_remaining -= speed (> 0 left)
+            nw_ = arrive ? w_arrive : nw_;
             const uint32_t sh = 8 * (k & 3);
             st[k >> 2] = arrive ? ((st[k >> 2] & ~(0xFFu << sh)) | ((uint32_t)turn << sh)) : st[k >> 2];
             gw[k] = nw_;
@@ -881,10 +887,13 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int n = 0; n < 12; ++n) L.u.A[n][lane] = 0;
     }
     int my_unit_score = 0, my_alive = 0;
+    int cntv[12];                      // alive units per group: also what the observation shows (:493)
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
         const uint32_t w = gw[k];
-        const int cnt = __popc(w & G_MASK_M);
+        int cnt = __popc(w & G_MASK_M);
+        asm volatile("" : "+v"(cnt));           // keep the count in its register for the observation (the compiler would recompute it there)
+        cntv[k] = cnt;
         const bool elig = ((w & G_MODE_M) >> G_MODE_S) != MODE_MOVING;                          // :720
         const uint32_t ctl = (uint32_t)((ctl_n >> (4 * k)) & 15u);
         const uint32_t add = (elig ? (uint32_t)cnt * ctl : 0u) | ((uint32_t)cnt << 16);
@@ -898,42 +907,47 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int part0 = 0, part1 = 0;          // score contributions of this lane's nodes to player 0 / player 1
     int base_cap = 0;
     {
+        // The pair splits the node IDs 0..11 in halves (player 0's lane: 0..5, where ID 0 does not exist; player 1's lane: 6..11), so
+        // every LDS address below is one per-lane base plus a constant.  controlledBy is kept in its stored form (+1: 0 = nobody).
+        const int nb = P ? 6 : 0;
         uint32_t a0v[6], a1v[6], nwv[6];
         int cpv[6], tsv[6];
+        const uint32_t* const pa = &L.u.A[nb][col & ~1];
+        const uint32_t* const pn = &L.NW[nb][E];
+        const int* const pc = &L.tab.cp[nb];
+        const int* const pt = &L.tab.ts[nb];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {                  // all LDS / table reads first, then pure ALU
-            const int n = (P ? 7 + j : 1 + j) % 12;    // j = 5 of player 1 is the unused slot 0
-            a0v[j] = L.u.A[n][col & ~1];
-            a1v[j] = L.u.A[n][col | 1];
-            nwv[j] = L.NW[n][E];
-            cpv[j] = L.tab.cp[n];
-            tsv[j] = L.tab.ts[n];
+            a0v[j] = pa[j * LPW];
+            a1v[j] = pa[j * LPW + 1];
+            nwv[j] = pn[j * (LPW / 2)];
+            cpv[j] = pc[j];
+            tsv[j] = pt[j];
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int n = P ? 7 + j : 1 + j;
-            const bool real = n <= NN;
+            const bool real = j > 0 || P != 0;
             int cs = (int)(nwv[j] & 0x3FFu) - 512;
-            int cb = (int)((nwv[j] >> 10) & 3u) - 1;
+            uint32_t cb1 = (nwv[j] >> 10) & 3u;                                    // controlledBy + 1
             const int cp = cpv[j], ts = tsv[j];
             const int pts0 = (int)(a0v[j] & 0xFFFFu), pts1 = (int)(a1v[j] & 0xFFFFu);
             const bool c0 = pts0 > 0, c1 = pts1 > 0;                               // ctr >= 1 (control >= 1)
-            const int pid = c0 ? 0 : 1;
-            const bool capture = real && play && (c0 != c1) && (abs(cs) < cp || pid != cb);   // :729-732
-            const int pxer = pid == 0 ? 1 : -1;
-            const int cs2 = cs + (pid == 0 ? pts0 : pts1) * pxer;                  // :748 (turn > 0 here)
-            const bool neutralize = (cs < 0) != (cs2 < 0);                         // :747-750
+            const uint32_t pid1 = c0 ? 1u : 2u;                                    // capturing player + 1
+            const bool capture = real && play && (c0 != c1) && (abs(cs) < cp || pid1 != cb1);   // :729-732
+            const int cs2 = cs + (pts0 - pts1);                                    // :748 (turn > 0 here): exactly one of the two is non-zero
+            const bool neutralize = (cs ^ cs2) < 0;                                // :747-750: the sign bit changed
             const bool full = abs(cs2) >= cp;                                      // :763-765
-            int cb2 = full ? pid : cb;
-            cb2 = (cb2 != -1 && neutralize) ? -1 : cb2;                            // :766-767
-            cs = capture ? (full ? cp * pxer : cs2) : cs;
-            cb = capture ? cb2 : cb;
-            if (capture) L.NW[n % 12][E] = (uint32_t)(cs + 512) | ((uint32_t)(cb + 1) << 10);
-            const bool bcap = real && ts != -1 && cb != -1 && cb != ts;            // :299-304
+            const uint32_t cb1n = neutralize ? 0u : (full ? pid1 : cb1);           // :766-767
+            const int csn = full ? (c0 ? cp : -cp) : cs2;
+            cs = capture ? csn : cs;
+            cb1 = capture ? cb1n : cb1;
+            if (capture) L.NW[nb + j][E] = (uint32_t)(cs + 512) | (cb1 << 10);
+            const bool bcap = real && ts != -1 && cb1 != 0u && (int)cb1 != ts + 1;  // :299-304
             base_cap |= bcap ? 1 : 0;
-            const int pts = real ? (abs(cs) == cp ? 2 * cp : abs(cs)) : 0;         // :305-310
-            part0 += (bcap && cb == 0 ? 1000 : 0) + (cs > 0 ? pts : 0);
-            part1 += (bcap && cb == 1 ? 1000 : 0) + (cs < 0 ? pts : 0);
+            const int acs = abs(cs);
+            const int pts = real ? acs + (acs == cp ? cp : 0) : 0;                 // :305-310
+            part0 += (bcap && cb1 == 1u ? 1000 : 0) + (cs > 0 ? pts : 0);
+            part1 += (bcap && cb1 == 2u ? 1000 : 0) + (cs < 0 ? pts : 0);
         }
     }
     // combine the pair: scores (server.py:291-317) and status (:321-328) are then known to both lanes
@@ -961,8 +975,12 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         rew0 = score[0] > score[1] ? 1.f : 0.f;
         rew1 = score[1] > score[0] ? 1.f : (score[0] > score[1] ? -1.f : 0.f);
     } else {
-        rew0 = (float)((double)score[0] / (double)EVG_MAX_SCORE);
-        rew1 = (float)((double)score[1] / (double)EVG_MAX_SCORE);
+        // scores[p] / 3700 (everglades_env.py:63-64) rounded to the float32 the reward tensor holds: the product with the rounded
+        // reciprocal differs from the float64 quotient by an ulp of float64 at most, which never crosses a float32 rounding
+        // boundary for an integer score below 2^22 (checked exhaustively: tests/test_abi_and_host.py)
+        constexpr double kInvMaxScore = 1.0 / (double)EVG_MAX_SCORE;
+        rew0 = (float)((double)score[0] * kInvMaxScore);
+        rew1 = (float)((double)score[1] * kInvMaxScore);
     }
     {
         // the output pointers are fetched together (one scalar-load batch), not one by one inside the branches below
@@ -1017,53 +1035,55 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int j = 0; j < 3; ++j) st[j] = 0;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) gw[k] = L.tab.init_grp[P * 12 + k];
+        for (int k = 0; k < 12; ++k) { gw[k] = L.tab.init_grp[P * 12 + k]; cntv[k] = __popc(gw[k] & G_MASK_M); }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int n = P ? 7 + j : 1 + j;
             if (n <= NN) L.NW[n][E] = L.tab.init_node[n];
         }
+        // ... and the units this side lists per node (what the opponent's observation shows): the whole army stands on its base
+#pragma unroll
+        for (int n = 0; n < 12; ++n) L.u.A[n][lane] = 0;
+        L.u.A[gw[0] & G_LOC_M][lane] = (uint32_t)NU << 16;
     }
     WAVE_SYNC();        // node words final; everybody is done adding to A
     PHASE(9);
 
     // ---------------- observation of this lane's player (board_state :382-455, player_state :457-501,
-    // everglades_env.py:158-171), written as int16 straight into the wave's output image in LDS
-    int cs_s[12], ou_s[12];
-    // an env that starts a new episode shows the game_init position (gw and the node words already hold it): the whole opposing
-    // army stands on its own base.  Branch-free (masks), so that the 22 LDS reads below stay one batch.
-    const uint32_t keep_units = do_reset ? 0u : ~0u;
-    const uint32_t opp_base = do_reset ? (L.tab.init_grp[(1 - P) * 12] & G_LOC_M) : 0xFFu;              // 0xFF: no such node
+    // everglades_env.py:158-171), written as int16 straight into the wave's output image in LDS.
+    // Board part by node ID (every LDS read has a constant offset): slot s of player 1's view shows node p1_node_map[s] (:437-439),
+    // so node n is written to slot p1inv[n]; player 0's view is the identity.
+    uint32_t nw_n[12], ou_n[12], res_n[12];
 #pragma unroll
-    for (int i = 1; i <= NN; ++i) {
-        const int n = P ? (int)((p1nib >> (4 * i)) & 15u) : i;                    // slot i of player 1 shows node p1_node_map[i] (:437-439)
-        cs_s[i] = (int)(L.NW[n][E] & 0x3FFu) - 512;                               // control sign not mirrored
-        const uint32_t listed = L.u.A[n][col ^ 1] >> 16;                         // opposing units listed at the node, moving ones included
-        ou_s[i] = (int)((listed & keep_units) | ((uint32_t)n == opp_base ? (uint32_t)NU : 0u));
+    for (int n = 1; n <= NN; ++n) {
+        nw_n[n] = L.NW[n][E];
+        ou_n[n] = L.u.A[n][col ^ 1];                    // high half: opposing units listed at the node, moving ones included (:446-449)
+        res_n[n] = (uint32_t)L.tab.res[n];              // DEFENSE flag | OBSERVE flag << 16
     }
+    const uint64_t slot_n = P ? L.tab.nib[10] : 0xBA9876543210ull;     // nibble n = board slot of node n in this player's view
+    const uint64_t own_n = P ? p1nib : 0xBA9876543210ull;              // nibble n = node n in this player's numbering (:485-486)
     WAVE_SYNC();        // A is dead from here on: the union becomes the output image
     int16_t* orow = &L.u.O[col * OBS];
     if (envlane) {
         orow[0] = (int16_t)turn;
 #pragma unroll
-        for (int i = 1; i <= NN; ++i) {
-            const int res = L.tab.res[P ? (int)((p1nib >> (4 * i)) & 15u) : i];
-            int16_t* o = orow + 1 + 4 * (i - 1);
-            o[0] = (res & EVG_RES_DEFENSE) ? 1 : 0;                                // :442
-            o[1] = (res & EVG_RES_OBSERVE) ? 1 : 0;                                // :443
-            o[2] = (int16_t)cs_s[i];
-            o[3] = (int16_t)ou_s[i];
+        for (int n = 1; n <= NN; ++n) {
+            int16_t* o = orow + 4 * (int)((slot_n >> (4 * n)) & 15u) - 3;
+            o[0] = (int16_t)(res_n[n] & 0xFFFFu);                                  // :442
+            o[1] = (int16_t)(res_n[n] >> 16);                                      // :443
+            o[2] = (int16_t)((int)(nw_n[n] & 0x3FFu) - 512);                       // control sign not mirrored
+            o[3] = (int16_t)(ou_n[n] >> 16);
         }
+        static_assert(MODE_MOVING == 2 && MODE_READY == 1 && MODE_IDLE == 0, "bit 1 of the mode field is the `moving` flag");
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
             const uint32_t w = gw[k];
-            const uint32_t loc = w & G_LOC_M;
             int16_t* o = orow + 45 + 5 * k;
-            o[0] = (int16_t)(P ? (uint32_t)((p1nib >> (4 * loc)) & 15u) : loc);    // :485-486
+            o[0] = (int16_t)((own_n >> (4 * (w & G_LOC_M))) & 15u);
             o[1] = (int16_t)((typ_n >> (4 * k)) & 15u);
             o[2] = (int16_t)((w & G_AVG_M) >> G_AVG_S);
-            o[3] = (int16_t)(((w & G_MODE_M) >> G_MODE_S) == MODE_MOVING ? 1 : 0);
-            o[4] = (int16_t)__popc(w & G_MASK_M);
+            o[3] = (int16_t)((w >> (G_MODE_S + 1)) & 1u);
+            o[4] = (int16_t)cntv[k];
         }
     }
     PHASE(10);

@@ -218,6 +218,13 @@ def test_create_rejects_bad_arguments_before_touching_a_device(evg):
     assert lib.evg_create(None, None) == -1
 
 
+def test_reward_by_reciprocal_equals_the_division_in_float32():
+    """The step kernel computes the non-terminal reward scores[p] / 3700 (everglades_env.py:63-64) as a float64 product with
+    the rounded reciprocal and stores float32: identical to the float32 rounding of the float64 quotient for every score."""
+    s = np.arange(0, 1 << 22, dtype=np.float64)
+    assert np.array_equal((s / 3700.0).astype(np.float32), (s * np.float64(1.0 / 3700.0)).astype(np.float32))
+
+
 def test_bench_window_helpers():
     """bench.py's desynchronising pre-roll: the episode phase of a global env id is the same function on the device (torch) and
     in the CPU replay (numpy), covers 0..149 about uniformly and is unrelated between neighbouring envs; the hash that ties

@@ -19,6 +19,7 @@ __global__ void __launch_bounds__(64) k(uint32_t* out, int iters, uint32_t seed)
     lds[threadIdx.x] = seed;
     const uint32_t s1 = seed | 1u;
     const double dk = 1.0000001, dm = 0.9999999;
+    if (MODE == 13) asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20", "s21");
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(64) k(uint32_t* out, int iters, uint32_t seed)
 #define X10(i) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[i]) : "v"(r[i]));
 #define X11(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(s1), "v"(seed));
 #define X12(i) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(r[i]) : "v"(s1));
-#define X13(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(s1) : "vcc");
+#define X13(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(r[i]) : "v"(s1));
 #define X14(i) asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(q[i]) : "v"(s1));
 #define X15(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[i]) : "v"(s1));
 #define X16(i) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r[i]) : "v"(r[(i + 1) & 7]));
@@ -84,8 +85,8 @@ int main() {
                              "ds_add_u32", "v_max_f64", "v_min_u32", "v_lshl_add_u64", "v_mad_u32_u24"};
     kern_t tab[30];
     Tab<29>::fill(tab);
-    const int iters = 500;
-    for (int wps = 1; wps <= 2; ++wps) {
+    const int iters = 20000;
+    for (int wps = 1; wps <= 4; wps *= 2) {
         const int grid = 1024 * wps;             // 1024 SIMDs
         printf("---- %d wave(s) per SIMD (%d workgroups of 64)\n", wps, grid);
         for (int m = 0; m < 30; ++m) {
@@ -99,7 +100,7 @@ int main() {
             }
             uint32_t cyc; hipMemcpy(&cyc, dmem + (1 << 20), 4, hipMemcpyDeviceToHost);
             const double n = (double)iters * 32.0;
-            printf("%-28s wave 0: %6.2f cycles per own instruction = %6.2f cycles per instruction issued on its SIMD   (%.3f ms)\n", names[m], cyc / n, cyc / n / wps, ms);
+            printf("%-28s wave 0: %6.2f cycles per own instruction = %6.2f cycles per instruction issued on its SIMD   (%.3f ms = %.2f cycles of 2.4 GHz per instruction per SIMD)\n", names[m], cyc / n, cyc / n / wps, ms, ms * 1e-3 * 2.4e9 / (n * wps));
             hipEventDestroy(e0); hipEventDestroy(e1);
         }
     }

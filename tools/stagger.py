@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import everglades_amd as evg
 N = 65536
-for a, b, h in ((21, 0, 0), (1, 0, 0), (13, 0, 0), (29, 0, 0), (21, 0, 0)):   # delay = slot x (a - 1) + simd x b sleeps of 256 cycles
+SWEEP = [int(x) for x in sys.argv[1:]] or [21, 1, 13, 29, 21]
+for a, b, h in [(a_, 0, 0) for a_ in SWEEP]:   # delay = slot x (a - 1) + simd x b sleeps of 256 cycles
     env = evg.EvergladesVecEnv(N, seed=1, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=(a << 8) | (b << 16)))
     env.reset()
     ids = torch.arange(N, device=env.device)
