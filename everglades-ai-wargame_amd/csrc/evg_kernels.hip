@@ -419,6 +419,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     WAVE_SYNC();
+    // Every prologue load is waited for here, before the turn loop: a register whose load may still be in flight on SOME path
+    // makes the compiler put s_waitcnt vmcnt(0) in front of its first use inside the loop, where it would wait for the previous
+    // turn's observation stores on every turn.
+    asm volatile("" :: "v"(episode), "v"(ep_ret), "v"(ag_cycle), "v"(ag_swarm), "v"(ag_dfs));
     const bool observe_only = io.observe_only != 0;
     // stock-entropy mode: the env's MT19937 is advanced by the lane of player 0, in the reference's draw order
     MtGen mt{nullptr, 0, 0};
@@ -467,7 +471,11 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         } else {                                        // on-device scripted agents of both seats (evg_rollout_policies, fused)
             const ChipView<LPW> view{&L, col, E, P, turn, p1nib};
-            agent_rows(P ? io.policy1 : io.policy0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, true, status == 0,
+            // both seats' policy ids as scalars, selected per lane (the compiler would otherwise turn the select into a per-lane
+            // global load from the argument segment, and wait for vmcnt(0) -- i.e. for last turn's stores -- in front of its use)
+            int pol0 = io.policy0, pol1 = io.policy1;
+            asm volatile("" : "+s"(pol0), "+s"(pol1));
+            agent_rows(P ? pol1 : pol0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, true, status == 0,
                        &ag_cycle, &ag_swarm, &ag_dfs, act);
             if (valid && (!MULTI || iter == nturns - 1)) {      // padding lanes of a partial last workgroup never write
                 const size_t ai_ = (size_t)P * N + e;
@@ -752,6 +760,13 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             WAVE_SYNC();
             PHASE(5);
 
+            // The prefetched rows are waited for HERE by every lane, used or not: a register with a load still in flight makes the
+            // compiler wait for vmcnt(0) wherever that register is written next (the movement phase), and vmcnt(0) also waits for
+            // the health stores of phase B to be acknowledged -- a full store round trip per turn.
+            if (kPrefetch) {
+#pragma unroll
+                for (int sl = 0; sl < 12; ++sl) asm volatile("" :: "v"(hpre[sl]));
+            }
             // Phase B (:573-644): one lane per fighting group; the uid-th alive unit of the snapshot (list-order
             // prefix + rank among the group's alive slots) takes its summed damage.  Both directions read only
             // the snapshot and the pool, so they are simultaneous like in the reference.
