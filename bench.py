@@ -39,8 +39,10 @@ SURVEY_ALGO_BYTES_PER_ENV_STEP = 4530
 # that were hit (64 B read + 64 B written per group row, 96 for group 11) -- see DESIGN.md section 3.
 MANDATORY_OUTPUT_BYTES = {"float32": 971, "float64": 971 + 840, "int16": 971 - 420}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0   # 1024 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes per cycle: what the
-                                                     # 78.6 TFLOP/s non-packed FP32 / FP64 vector peak amounts to; SQ_ACTIVE_INST_VALU agrees), 2.4 GHz
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0   # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction: what a SIMD sustains with 2 or 4
+                                                     # waves on this kernel's instruction mix (tools/micro/inst_rate.hip, profiles/r02_q_*: 4.3-4.8 cycles per
+                                                     # instruction per SIMD for mul / f64 / bfe / perm / cndmask / DPP, 2.7 for plain add / xor; the guide's
+                                                     # 2-cycle SIMD-32 issue holds for the simplest ops only).  SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction.
 PHASES = 150                 # episode length of random vs random (server.py:321): the pre-roll spreads phases over it
 
 

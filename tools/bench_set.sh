@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run on the GPU box through gpurun:  bash tools/bench_set.sh <tag>
+# The bench lines kept under profiles/: default run, the driver's short shape, BASELINE config 5 (scripted bots, fused), the
+# 4 096-env configuration and int16 observations.  Each is ONE JSON line in gpurun_out/bench_<tag>_<name>.json.
+set -o pipefail
+TAG=${1:-r02}
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+run() { name=$1; shift; timeout -k 10 400 python bench.py "$@" > gpurun_out/bench_${TAG}_$name.json 2> gpurun_out/bench_${TAG}_$name.err || { tail -5 gpurun_out/bench_${TAG}_$name.err; exit 1; }; }
+run final
+run driver_shape --steps 20 --warmup 5
+run config5 --workload scripted --no-cpu-baseline
+run 4096envs --envs 4096 --no-cpu-baseline
+run int16 --obs-dtype int16 --no-cpu-baseline
+python - <<P
+import json, glob
+for f in sorted(glob.glob("gpurun_out/bench_${TAG}_*.json")):
+    d = json.loads(open(f).read())
+    o = d["config"].get("one_launch_per_turn") or {}
+    print("%-28s %.3f G env-steps/s  %.2f us/step  roofline.frac %s  hash %s  per-turn %.3f G" % (f.split("bench_")[1], d["value"] / 1e9, d["ms_per_step"] * 1e3,
+          d["roofline"].get("frac"), d["config"].get("kernel_source_hash"), o.get("env_steps_per_s", 0) / 1e9))
+P
