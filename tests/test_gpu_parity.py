@@ -721,7 +721,7 @@ def test_evaluate_harness_matches_sequential_semantics(evg, oracle_mod):
 
 def _custom_tables(evg, oracle_mod):
     """A table set that differs from DemoMap / UnitDefinitions in every runtime table: distances, control points, node
-    defenses (non-dyadic), resources, unit stats.  Returns (device tables, oracle tables) with identical contents."""
+    defenses (non-dyadic), resources, unit stats, player 1's node map.  Returns (device tables, oracle tables) with identical contents."""
     import ctypes as C
     t = evg.default_tables()
     conn = {1: {2: 5, 4: 7}, 2: {1: 5, 3: 3, 5: 6}, 3: {2: 3, 4: 2, 5: 4, 6: 5, 7: 4}, 4: {1: 7, 3: 2, 7: 6},
@@ -736,6 +736,10 @@ def _custom_tables(evg, oracle_mod):
     for u, (h, d, s, c, k) in enumerate([(5, 1, 2, 3, 2), (3, 2, 1, 1, 3), (2, 3, 3, 2, 1)]):
         t.unit_health[u], t.unit_damage[u], t.unit_speed[u], t.unit_control[u], t.unit_cost[u] = h, d, s, c, k
     t.max_turns = 97
+    # a board flip that is NOT its own inverse (DemoMap's is): slot s of player 1's view shows node map[s], so node n sits in slot
+    # inverse[n], while a group's location and an order's node id go through map itself (server.py:437-439, :485-486, :233-234)
+    for i, v in enumerate([0, 11, 8, 9, 10, 6, 7, 5, 2, 3, 4, 1]):
+        t.p1_node_map[i] = v
     ot = oracle_mod.Tables()
     assert C.sizeof(ot) == C.sizeof(t)
     C.memmove(C.byref(ot), C.byref(t), C.sizeof(t))
