@@ -11,6 +11,7 @@ through the C oracle and through the HIP path.
 
     python oracle/gen_golden.py            # regenerate everything but the 10 000-match sample (about 2 minutes)
     EVG_GOLDEN_ONLY=matches python oracle/gen_golden.py    # tests/golden/matches_10k.npz (about 10 minutes on 6 cores)
+    EVG_GOLDEN_ONLY=matches5 python oracle/gen_golden.py   # tests/golden/matches_config5_10k.npz (Cycle_BRush_Turn25 vs SwarmAgent)
 
 Loader recipe: SURVEY.md Appendix B (np.int alias; a stub `gym` package so the real
 gym_everglades/envs/everglades_env.py imports unmodified).
@@ -690,7 +691,52 @@ def _match_worker(span):
     return lo, out
 
 
-def gen_matches_fixture(procs=6, chunk=50):
+def _match_worker_config5(span):
+    """BASELINE config 5 played by the reference's own agent classes: seat 0 = Cycle_BRush_Turn25 (cycle_rush_turn25.py),
+    seat 1 = SwarmAgent (swarm_agent.py), fresh agent objects per game (one episode per env), the harness loop of
+    evaluate.py:127-160; agent and combat entropy injected as in play_agents.  Only outcomes are kept."""
+    global _match_runner
+    if _match_runner is None:
+        _match_runner = Runner()
+    R = _match_runner
+    lo, hi = span
+    n = hi - lo
+    out = dict(length=np.zeros(n, np.int16), scores=np.zeros((n, 2), np.int32), status=np.zeros(n, np.uint8),
+               reward=np.zeros((n, 2), np.float64), returns=np.zeros((n, 2), np.float64), winner=np.zeros(n, np.int8),
+               obs_final_sum=np.zeros((n, 2), np.int32), alive_final=np.zeros((n, 2), np.int16), draws=np.zeros(n, np.int32))
+    seats = (("cycle_rush_turn25.py", "Cycle_BRush_Turn25"), ("swarm_agent.py", "SwarmAgent"))
+    for i in range(n):
+        env_id = lo + i
+        agents = [load_agent(R.proxy, fn, cn, p) for p, (fn, cn) in enumerate(seats)]
+        obs = R.reset(MATCH_SEED, env_id, 0)
+        game = R.env.game
+        box = {}
+        orig = game.game_turn
+
+        def wrapped(actions, _o=orig, _b=box):
+            s, st = _o(actions)
+            _b["scores"], _b["status"] = (int(s[0]), int(s[1])), int(st)
+            return s, st
+
+        game.game_turn = wrapped
+        d0 = R.proxy.draws
+        done, t, ret = 0, 0, [0.0, 0.0]
+        while not done:
+            acts = {p: np.array(agents[p].get_action(obs[p]), dtype=np.float64) for p in (0, 1)}
+            obs, reward, done, info = R.env.step(acts)
+            ret[0] += float(reward[0]); ret[1] += float(reward[1])
+            t += 1
+        out["length"][i], out["scores"][i], out["status"][i] = t, box["scores"], box["status"]
+        out["reward"][i] = [float(reward[0]), float(reward[1])]
+        out["returns"][i] = ret
+        out["winner"][i] = 0 if reward[0] > reward[1] else (2 if reward[0] == reward[1] else 1)      # evaluate.py:155-160
+        out["obs_final_sum"][i] = [int(np.sum(obs[0])), int(np.sum(obs[1]))]
+        out["alive_final"][i] = [int(np.sum(obs[p][49::5])) for p in (0, 1)]
+        out["draws"][i] = R.proxy.draws - d0
+    return lo, out
+
+
+def gen_matches_fixture(procs=6, chunk=50, worker=None, fname="matches_10k.npz"):
     """tests/golden/matches_10k.npz: BASELINE north_star "bit-identical win counts vs the CPU reference over 10 000
     seeded matches" -- env ids 0..9999 of seed MATCH_SEED, episode 0, one game each, played by the imported reference."""
     import multiprocessing as mp
@@ -698,7 +744,7 @@ def gen_matches_fixture(procs=6, chunk=50):
     spans = [(lo, min(lo + chunk, MATCH_COUNT)) for lo in range(0, MATCH_COUNT, chunk)]
     parts = {}
     with mp.get_context("fork").Pool(procs) as pool:
-        for k, (lo, o) in enumerate(pool.imap_unordered(_match_worker, spans)):
+        for k, (lo, o) in enumerate(pool.imap_unordered(worker or _match_worker, spans)):
             parts[lo] = o
             if k % 10 == 9:
                 print("matches: %d / %d games, %.0fs" % ((k + 1) * chunk, MATCH_COUNT, time.time() - t0), flush=True)
@@ -707,8 +753,8 @@ def gen_matches_fixture(procs=6, chunk=50):
     d["seed"] = np.array([MATCH_SEED], np.uint64)
     w = d["winner"]
     d["wins_p0_p1_tie"] = np.array([int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum())], np.int32)
-    np.savez_compressed(os.path.join(OUT, "matches_10k.npz"), **d)
-    print("matches_10k: wins p0/p1/tie", d["wins_p0_p1_tie"].tolist(), "status histogram", np.bincount(d["status"], minlength=4).tolist(),
+    np.savez_compressed(os.path.join(OUT, fname), **d)
+    print(fname, "wins p0/p1/tie", d["wins_p0_p1_tie"].tolist(), "status histogram", np.bincount(d["status"], minlength=4).tolist(),
           "mean length %.2f" % d["length"].mean(), "%.0fs" % (time.time() - t0), flush=True)
 
 
@@ -752,6 +798,9 @@ def main():
         return
     R = Runner()
     stats = {}
+    if os.environ.get("EVG_GOLDEN_ONLY") == "matches5":      # BASELINE config 5, the reference's own agent classes
+        gen_matches_fixture(worker=_match_worker_config5, fname="matches_config5_10k.npz")
+        return
     if os.environ.get("EVG_GOLDEN_ONLY") == "agents":
         gen_agent_fixtures(R)
         return

@@ -837,6 +837,36 @@ def test_ten_thousand_reference_matches_on_device(evg):
     env.close()
 
 
+def test_ten_thousand_reference_matches_config5_on_device(evg):
+    """BASELINE config 5 against the reference itself: the 10 000 matches of tests/golden/matches_config5_10k.npz (the reference's
+    own Cycle_BRush_Turn25 and SwarmAgent classes on the reference's server) replayed by ONE 10 000-env handle with both bots fused
+    into the step kernel (persistent form, one launch of 150 turns, finished games frozen): every game and the win counts, bit for
+    bit; then once more with the standalone agent kernel and one evg_step per turn."""
+    from test_oracle_golden import check_matches
+    d = load_golden("matches_config5_10k.npz")
+    n = len(d["length"])
+    env = evg.EvergladesVecEnv(n, seed=int(d["seed"][0]), env_id_base=0, obs_dtype="float64", auto_reset=False)
+    env.reset()
+    obs, rew, done, info = env.rollout_policies(150, "cycle_rush_turn25", "swarm", turns_per_launch=150)
+    assert int(done.sum()) == n
+    st = env.episode_stats()
+    o = _np(obs)
+    got = dict(length=st["length"].astype(np.int16), scores=_np(info["scores"]), status=_np(info["status"]), reward=_np(rew).astype(np.float64),
+               returns=st["returns"].astype(np.float64), winner=st["winner"], obs_final_sum=o.sum(axis=2).astype(np.int32),
+               alive_final=o[:, :, 49::5].sum(axis=2).astype(np.int16))
+    check_matches(got, d)
+    assert st["totals"].tolist() == [n] + d["wins_p0_p1_tie"].tolist()
+    env.close()
+    env = evg.EvergladesVecEnv(n, seed=int(d["seed"][0]), env_id_base=0, auto_reset=False)
+    env.reset()
+    for _ in range(150):
+        env.scripted_actions("cycle_rush_turn25", 0)
+        obs, rew, done, info = env.step(env.scripted_actions("swarm", 1))
+    st2 = env.episode_stats()
+    assert np.array_equal(st2["winner"], d["winner"]) and np.array_equal(st2["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"])
+    env.close()
+
+
 def _compare_whole_batch(env, ora, o_obs, what):
     """every env of the batch: packed state (groups incl. arrival stamps, nodes, float64 health, turn/status/episode), observations and
     the results of the last finished episode"""

@@ -269,3 +269,25 @@ def test_ten_thousand_reference_matches(oracle_mod):
             return obs.sum(axis=2).astype(np.int32), obs[:, :, 49::5].sum(axis=2).astype(np.int16), info["scores"], info["status"], rew, done
         return step
     check_matches(play_matches(make, d), d)
+
+
+def test_ten_thousand_reference_matches_config5(oracle_mod):
+    """BASELINE config 5 against the reference itself: 10 000 seeded matches of the reference's own agent classes
+    (cycle_rush_turn25.py Cycle_BRush_Turn25 on seat 0, swarm_agent.py SwarmAgent on seat 1; oracle/gen_golden.py,
+    EVG_GOLDEN_ONLY=matches5).  The oracle's restatement of both agents and of the game reproduces every match and the win counts."""
+    d = load_golden("matches_config5_10k.npz")
+    assert len(d["length"]) == 10000 and d["wins_p0_p1_tie"].sum() == 10000
+
+    def make(n, seed):
+        o = oracle_mod.Oracle(n, seed=seed, env_id_base=0)
+        cur = [o.reset()]
+
+        def step(t):
+            a = np.zeros((n, 2, 7, 2), np.int32)
+            o.scripted_actions(1, 0, cur[0], a)          # EVG_POLICY_CYCLE_RUSH_25
+            o.scripted_actions(3, 1, cur[0], a)          # EVG_POLICY_SWARM
+            obs, rew, done, info = o.step(a)
+            cur[0] = obs
+            return obs.sum(axis=2).astype(np.int32), obs[:, :, 49::5].sum(axis=2).astype(np.int16), info["scores"], info["status"], rew, done
+        return step
+    check_matches(play_matches(make, d), d)
