@@ -202,7 +202,9 @@ static void fill_lds_tables(DevTables* D) {
     L.nib[0] = D->p1map_nib;
     for (int p = 0; p < NP; ++p) { L.nib[1 + p] = D->speed_nib[p]; L.nib[3 + p] = D->control_nib[p]; L.nib[5 + p] = D->cost_nib[p]; L.nib[7 + p] = D->type_nib[p]; }
     L.nib[10] = D->p1inv_nib;
-    L.nib[11] = 0;
+    L.nib[11] = D->maxnbr_nib;
+    L.nib[12] = D->tar_to_1;
+    L.nib[13] = D->tar_to_11;
     L.nib[9] = (uint64_t)(uint32_t)D->max_turns | ((uint64_t)(D->damage_nib & 0xFFFFu) << 8) | ((uint64_t)(D->fast_div ? 1u : 0u) << 24);
 }
 

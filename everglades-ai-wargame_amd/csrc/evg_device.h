@@ -45,8 +45,9 @@ struct __attribute__((aligned(16))) LdsTables {
     int32_t  cp[12], ts[12], res[12];       // control points, team start by node ID; res = the two board flags as the observation
                                             // shows them: (DEFENSE ? 1 : 0) | (OBSERVE ? 1 : 0) << 16 (server.py:442-443)
     uint32_t init_grp[24], init_node[12];   // state right after game_init (auto-reset inside the kernel)
-    uint64_t nib[12];            // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24;
-                                 // [10] = p1inv (nibble n = slot of player 1's board view that shows node n); [11] unused
+    uint64_t nib[14];            // p1map, speed[2], control[2], cost[2], type[2] nibble tables; [9] = max_turns | damage_nib << 8 | fast_div << 24;
+                                 // [10] = p1inv (nibble n = slot of player 1's board view that shows node n); [11] = maxnbr_nib,
+                                 // [12] = tar_to_1, [13] = tar_to_11 (the scripted bots' routing tables, see DevTables)
 };
 static_assert(sizeof(LdsTables) % 16 == 0, "the kernel copies the blob in 16-byte pieces");
 

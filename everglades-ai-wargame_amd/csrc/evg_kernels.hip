@@ -177,8 +177,16 @@ __device__ __forceinline__ void cycle_advance(int& group_num, int& node_num) {
     if (group_num == 0) node_num = node_num % NN + 1;
 }
 
+// the routing tables the bots index: in the step kernel they come from the LDS copy (a load from the global table would be a
+// per-lane vector load -- the kernel stores to global memory, so the compiler cannot keep it scalar -- and waiting for it
+// means vmcnt(0): for the previous turn's observation stores as well)
+struct AgentTabs {
+    uint64_t maxnbr, tar1, tar11;       // DevTables::maxnbr_nib, tar_to_1, tar_to_11
+    const DevTables* T;                 // dfs_attack's order sequence stays in global memory (that bot only)
+};
+
 template <class View>
-__device__ __forceinline__ void agent_rows(int policy, const View& v, const DevTables* T, uint32_t seed_lo, uint32_t seed_hi, uint32_t env_id,
+__device__ __forceinline__ void agent_rows(int policy, const View& v, const AgentTabs& tabs, uint32_t seed_lo, uint32_t seed_hi, uint32_t env_id,
                                            uint32_t episode, int player, bool commit, bool active, uint32_t* p_cycle, uint32_t* p_swarm, uint32_t* p_dfs, int2 (&rows)[NA]) {
     // `commit` is false for the padding lanes of a partial last workgroup (they compute like everyone else but must not
     // advance the agent state of the env their indices are clamped to) and for a finished, not yet reset game: the harness
@@ -239,7 +247,7 @@ __device__ __forceinline__ void agent_rows(int policy, const View& v, const DevT
                     cycle_advance(group_num, node_num);
                 } else {
                     const int cur = v.loc(group_num);
-                    const int nx = (int)(((tar == 1 ? T->tar_to_1 : T->tar_to_11) >> (4 * cur)) & 15ull);   // 15 encodes the bots' -1
+                    const int nx = (int)(((tar == 1 ? tabs.tar1 : tabs.tar11) >> (4 * cur)) & 15ull);   // 15 encodes the bots' -1
                     rows[i] = make_int2(group_num, nx == 15 ? -1 : nx);
                     group_num = (group_num + 1) % NG;
                 }
@@ -250,8 +258,8 @@ __device__ __forceinline__ void agent_rows(int policy, const View& v, const DevT
         // dfs_attack.py ignores the observation: its orders are an eventually periodic sequence of the call count,
         // tabulated on the host at evg_create (including the rows that persist in its mutable default argument)
         const uint32_t c = *p_dfs;
-        const uint32_t idx = c < (uint32_t)T->dfs_mu ? c : (uint32_t)T->dfs_mu + (c - (uint32_t)T->dfs_mu) % (uint32_t)T->dfs_lambda;
-        const uint64_t r = T->dfs_rows[idx];
+        const uint32_t idx = c < (uint32_t)tabs.T->dfs_mu ? c : (uint32_t)tabs.T->dfs_mu + (c - (uint32_t)tabs.T->dfs_mu) % (uint32_t)tabs.T->dfs_lambda;
+        const uint64_t r = tabs.T->dfs_rows[idx];
 #pragma unroll
         for (int i = 0; i < NA; ++i) rows[i] = make_int2((int)((r >> (8 * i)) & 15ull), (int)((r >> (8 * i + 4)) & 15ull));
         if (commit) *p_dfs = c + 1u;
@@ -273,7 +281,7 @@ __device__ __forceinline__ void agent_rows(int policy, const View& v, const DevT
         if (commit) *p_swarm = lst;
 #pragma unroll
         for (int i = 0; i < NA; ++i) rows[i] = make_int2(0, 1);            // np.tile([0, 1], (7, 1))
-        const uint64_t mx = T->maxnbr_nib;
+        const uint64_t mx = tabs.maxnbr;
         int n = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -475,7 +483,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // global load from the argument segment, and wait for vmcnt(0) -- i.e. for last turn's stores -- in front of its use)
             int pol0 = io.policy0, pol1 = io.policy1;
             asm volatile("" : "+s"(pol0), "+s"(pol1));
-            agent_rows(P ? pol1 : pol0, view, T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, true, status == 0,
+            const AgentTabs atabs{L.tab.nib[11], L.tab.nib[12], L.tab.nib[13], T};
+            agent_rows(P ? pol1 : pol0, view, atabs, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, true, status == 0,
                        &ag_cycle, &ag_swarm, &ag_dfs, act);
             if (valid && (!MULTI || iter == nturns - 1)) {      // padding lanes of a partial last workgroup never write
                 const size_t ai_ = (size_t)P * N + e;
@@ -1284,7 +1293,8 @@ __global__ void __launch_bounds__(256) evg_scripted_actions_kernel(DevState S, i
     const size_t ai = (size_t)player * S.N + e;
     const ObsView<OT> v{obs + ((size_t)e * 2 + player) * OBS};
     int2 rows[NA];
-    agent_rows(policy, v, S.T, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, S.episode[e], player, true, ((S.env[e] >> 8) & 3u) == 0u, S.agent_cycle + ai, S.agent_swarm + ai,
+    const AgentTabs atabs{S.T->maxnbr_nib, S.T->tar_to_1, S.T->tar_to_11, S.T};
+    agent_rows(policy, v, atabs, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, S.episode[e], player, true, ((S.env[e] >> 8) & 3u) == 0u, S.agent_cycle + ai, S.agent_swarm + ai,
                S.agent_dfs + ai, rows);
     int2* out = reinterpret_cast<int2*>(actions) + ((size_t)e * 2 + player) * NA;
 #pragma unroll

@@ -31,9 +31,11 @@ for upto in ((20, 50, 80) if SCRIPTED else (20, 80, 140)):
     st = np.zeros((nb_buf, 16), np.uint64)
     assert L.evg_debug_read_stamps(env._h, st.ctypes.data_as(C.c_void_p)) == 0
     st = st[:nb]
-    d = np.diff(st[:, :14].astype(np.int64), axis=1)
-    d = np.where(d < 0, 0, d)      # stamps inside the skipped combat block keep older values
-    tot = (st[:, 13] - st[:, 0]).astype(np.int64)
+    st = st.astype(np.int64)
+    for i in range(1, 14):         # a wave that skips the combat block keeps that block's stamps of an earlier turn: older than its
+        st[:, i] = np.maximum(st[:, i], st[:, i - 1])   # own stamp before -> the phase counts as empty
+    d = np.diff(st[:, :14], axis=1)
+    tot = st[:, 13] - st[:, 0]
     span = int(st[:, 13].max() - st[:, 0].min())
     print("turn %d: mean wave %.0f cycles (max %.0f), first-start to last-end %d cycles (memtime ticks, 100 MHz => x10 ns)" % (upto, tot.mean(), tot.max(), span))
     for i, nm in enumerate(NAMES):
