@@ -16,7 +16,7 @@ every timed turn sees the episode-average mix of early (few fights) and late (ma
 
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); environments shard by
 contiguous global id (weak scaling: 65 536 per GPU) and the only collective is the gather of episode
-results (RCCL all-gather over xGMI).  Rank 0 prints ONE JSON line.
+results (one RCCL gather to rank 0 over xGMI, 16 bytes per env).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import glob
@@ -248,10 +248,10 @@ def main():
         return env, rollout
 
     env, rollout = make_env(args.obs_dtype)
-    stats_dev = env.episode_stats_device()
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
-    if world > 1:      # first use opens the RCCL channels and loads torch's small kernels: not part of the timed region
-        evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
+    gather = evg.ResultGather(n_local, total, device)          # preallocated buffers; rank 0 receives (one RCCL gather)
+    if world > 1:      # first use opens the RCCL channels: not part of the timed region
+        gather(env.packed_episode_results(out=gather.buffer))
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch)
         played += args.warmup
@@ -262,8 +262,8 @@ def main():
     t0 = time.perf_counter()
     kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch)
     gathered = None
-    if world > 1:
-        gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
+    if world > 1:      # one pack kernel + one gather of 16 B per env to rank 0
+        gathered = gather(env.packed_episode_results(out=gather.buffer))
     barrier()
     dt_local = time.perf_counter() - t0
     played += args.steps
@@ -278,8 +278,8 @@ def main():
         dt = max(p["seconds"] for p in per_rank)
     step_kernel_ms = kernel_ms_sum / args.steps
     st = env.episode_stats()
-    if gathered is None:
-        gathered = evg.gather_episode_results(stats_dev["returns"], stats_dev["length"], stats_dev["winner"], total, count_wins=False)
+    if world == 1:
+        gathered = gather(env.packed_episode_results())
     final_state = env.get_state() if (world == 1 and not args.no_cpu_baseline and args.workload == "random" and played <= 2000) else None
 
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
@@ -364,13 +364,13 @@ def main():
                        "kernel_source_hash": kernel_source_hash(),
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
-                       "gathered_wins_all_ranks": list(evg.win_counts(gathered)) if gathered is not None else None},
+                       "gathered_wins_all_ranks": list(evg.ResultGather.win_counts(gathered)) if gathered is not None else None},
             "roofline": roof,
         }
         if valu:
             out["roofline_valu_issue"] = valu
         if world > 1:
-            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "all_gather of [n,4] f32 episode results",
+            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "one pack kernel + torch.distributed.gather of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather), inside the timed region",
                                   "per_rank": per_rank}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed)

@@ -10,11 +10,11 @@ from ._lib import EvgError, load as load_library
 from .tables import default_tables, tables_from_json
 from .vec_env import EvergladesVecEnv
 from .env import EvergladesEnv, canonical_actions
-from .distributed import shard_range, gather_episode_results, win_counts
+from .distributed import shard_range, gather_episode_results, win_counts, ResultGather
 from .harness import evaluate, evaluate_all, proportion_confint_normal
 
 __all__ = ["EvergladesVecEnv", "EvergladesEnv", "EvgError", "load_library", "default_tables", "tables_from_json",
-           "canonical_actions", "shard_range", "gather_episode_results", "win_counts", "evaluate", "evaluate_all",
+           "canonical_actions", "shard_range", "gather_episode_results", "win_counts", "ResultGather", "evaluate", "evaluate_all",
            "proportion_confint_normal"]
 
 try:  # optional: same gym id as the reference (gym_everglades/__init__.py:3-6) when gym is installed

@@ -798,6 +798,15 @@ int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
 }
 #endif
 
+int evg_pack_episode_results(evg_handle* h, float* out, void* stream) {
+    if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
+    if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0) return fail(EVG_ERR_INVALID, "out must be 16-byte aligned");
+    EVG_ON_DEVICE(h);
+    const int rc = launch_pack_results(h->S, out, stream);
+    if (rc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
 int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (returns) *returns = h->S.fin_ret;

@@ -1217,6 +1217,16 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #undef io
 
 // ---------------------------------------------------------------------------------------------
+// per-env results of the last finished episode, packed for the path's one exchange: 16 bytes per env
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) evg_pack_results_kernel(DevState S, float4* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S.N) return;
+    const float2 r = reinterpret_cast<const float2*>(S.fin_ret)[e];
+    out[e] = make_float4(r.x, r.y, (float)S.fin_win[e], (float)S.fin_len[e]);      // small integers are exact in float32
+}
+
+// ---------------------------------------------------------------------------------------------
 // reset (everglades_env.py:75-116 -> server.py:133-209): masked, per env
 // ---------------------------------------------------------------------------------------------
 template <typename OT>
@@ -1532,6 +1542,11 @@ int launch_smart_state(const DevState& S, int player, const void* obs, float* ou
 
 int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, int8_t* sight, void* stream) {
     hipLaunchKernelGGL(evg_fog_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, fog, know, sight);
+    return (int)hipGetLastError();
+}
+
+int launch_pack_results(const DevState& S, float* out, void* stream) {
+    hipLaunchKernelGGL(evg_pack_results_kernel, dim3((S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, reinterpret_cast<float4*>(out));
     return (int)hipGetLastError();
 }
 

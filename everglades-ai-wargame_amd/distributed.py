@@ -5,6 +5,8 @@ tests).  Rank r owns the contiguous env range `shard_range(total, world, r)`; en
 every random stream -- are global, so results do not depend on the number of GPUs.  The only exchange
 is ONE gather of per-episode results ({return[2], winner, length} per env, 16 bytes) at episode
 boundaries: about 1 MB per GPU at 65 536 envs, far below what one xGMI link moves in a millisecond.
+`ResultGather` is the preallocated form bench.py times (one pack kernel + one `gather` to rank 0);
+`gather_episode_results` is the convenience form that leaves the full result on every rank (all-gather).
 """
 
 
@@ -52,6 +54,70 @@ def gather_episode_results(returns, length, winner, total_envs=None, group=None,
     if count_wins:
         out["wins"] = win_counts(out)
     return out
+
+
+class ResultGather:
+    """The path's one exchange with everything preallocated: rank `dst` receives the packed per-env results
+    (`EvergladesVecEnv.packed_episode_results()`: float32 [n_local, 4] = return p0, return p1, winner, length) of every rank,
+    in global env order, with ONE collective -- `torch.distributed.gather` (RCCL: every rank sends its 16 B/env straight to
+    `dst` over its own xGMI link; nothing is sent to ranks that do not need it) -- and no other kernel.  Shards that differ
+    by one env (total not divisible by the world size) are padded to a common width.  With the gloo backend (CPU tests, or
+    a rehearsal on one GPU) the collective runs on host copies.
+
+        g = ResultGather(n_local, total, device)           # once
+        full = g(env.packed_episode_results(out=g.buffer)) # [total, 4] on rank dst, None elsewhere (g.buffer: the send buffer
+                                                           # itself, so that the pack kernel writes where the collective reads)
+        wins = ResultGather.win_counts(full)               # (p0, p1, ties, unfinished)
+    """
+
+    def __init__(self, n_local, total_envs, device, group=None, dst=0):
+        import torch
+        import torch.distributed as dist
+        self.group, self.dst, self.total = group, int(dst), int(total_envs)
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.counts = [shard_range(self.total, self.world, r)[1] for r in range(self.world)]
+        assert self.counts[self.rank] == int(n_local), "local shard size does not match shard_range()"
+        self.width = max(self.counts)
+        self.host = self.on and dist.get_backend(group) == "gloo"
+        dev = torch.device("cpu") if self.host else torch.device(device)
+        self.home = torch.device(device)
+        self.send = torch.zeros((self.width, 4), dtype=torch.float32, device=dev) if self.on else None
+        self.recv = torch.empty((self.world, self.width, 4), dtype=torch.float32, device=dev) if (self.on and self.rank == self.dst) else None
+        self.parts = list(self.recv.unbind(0)) if self.recv is not None else None
+        # where the local rows should be written to spare the copy into the send buffer (None: pass any [n_local, 4] tensor)
+        self.buffer = self.send[:self.counts[self.rank]] if (self.on and not self.host) else None
+
+    def __call__(self, packed):
+        """packed: float32 [n_local, 4] on this rank's device.  Returns [total, 4] on rank dst (a view of the receive buffer when
+        all shards have the same size), None on the other ranks; the input itself without a process group."""
+        import torch
+        import torch.distributed as dist
+        if not self.on:
+            return packed
+        n = self.counts[self.rank]
+        if self.buffer is None or packed.data_ptr() != self.buffer.data_ptr():
+            self.send[:n].copy_(packed, non_blocking=not self.host)
+        dist.gather(self.send, self.parts, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        if all(c == self.width for c in self.counts):
+            full = self.recv.view(self.world * self.width, 4)
+        else:
+            full = torch.cat([self.recv[r, :c] for r, c in enumerate(self.counts)], dim=0)
+        return full.to(self.home) if self.host and self.home.type != "cpu" else full
+
+    @staticmethod
+    def split(full):
+        """dict(returns [total, 2] f32, winner int8, length int32) of a gathered [total, 4] tensor"""
+        import torch
+        return dict(returns=full[:, :2], winner=full[:, 2].to(torch.int8), length=full[:, 3].to(torch.int32), wins=None)
+
+    @staticmethod
+    def win_counts(full):
+        w = full[:, 2].to("cpu")
+        return (int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum()))
 
 
 def win_counts(gathered):

@@ -339,6 +339,20 @@ class EvergladesVecEnv(object):
         return dict(returns=view(pr, (N, 2), torch.float32, 4), length=view(pl, (N,), torch.int32, 4),
                     winner=view(pw, (N,), torch.int8, 1))
 
+    def packed_episode_results(self, out=None):
+        """The per-env results of the last finished episode as ONE float32 [N, 4] tensor {return p0, return p1, winner, length}
+        (evg_pack_episode_results: one small kernel on the current stream): the payload of the path's single exchange between
+        GPUs (`distributed.ResultGather`).  `out`: a float32 [N, 4] CUDA tensor to fill (default: a buffer owned by the env)."""
+        torch = _torch()
+        if out is None:
+            if getattr(self, "_packed", None) is None:
+                self._packed = torch.empty((self.num_envs, 4), dtype=torch.float32, device=self.device)
+            out = self._packed
+        else:
+            out = self._user(out, (self.num_envs, 4), torch.float32, "out")
+        self._check(self.L.evg_pack_episode_results(self._h, self._ptr(out), self._stream()))
+        return out
+
     @property
     def state_bytes_per_env(self):
         return int(self.L.evg_state_bytes_per_env(self._h))

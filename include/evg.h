@@ -272,6 +272,10 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
 /* Device pointers to the same per-env arrays (returns float[N][2], length int32[N], winner int8[N]),
  * for the multi-GPU gather of episode returns without a host round trip. */
 int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner);
+/* The same per-env results packed for the path's ONE exchange between GPUs (the win bookkeeping of
+ * evaluate.py:155-181 then runs on the gathered rows): out[e] = {return of player 0, return of player 1, winner, length} as
+ * float32 (the small integers are exact), 16 bytes per env, written on `stream`.  out: device memory, [N][4], 16-byte aligned. */
+int evg_pack_episode_results(evg_handle* h, float* out, void* stream);
 
 int evg_num_envs(const evg_handle* h);
 /* bytes of persistent device state per env (for the roofline accounting in DESIGN.md) */

@@ -70,3 +70,38 @@ def test_gather_without_process_group_is_identity():
     r = torch.arange(10, dtype=torch.float32).reshape(5, 2)
     g = evg.gather_episode_results(r, torch.full((5,), 150, dtype=torch.int32), torch.tensor([0, 1, 2, 0, -1], dtype=torch.int8))
     assert torch.equal(g["returns"], r) and g["wins"] == (2, 1, 1, 1) and g["length"].tolist() == [150] * 5
+
+
+def _worker_dst(rank, world, port, outdir, total):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import everglades_amd as evg
+    first, cnt = evg.shard_range(total, world, rank)
+    st = _rollout(cnt, first)
+    packed = evg.distributed.pack_episode_results(torch.from_numpy(st["returns"]), torch.from_numpy(st["length"]), torch.from_numpy(st["winner"]))
+    g = evg.ResultGather(cnt, total, "cpu", dst=0)
+    for _ in range(2):                           # the buffers are reused from call to call
+        full = g(packed)
+    assert (full is None) == (rank != 0)
+    if rank == 0:
+        d = evg.ResultGather.split(full)
+        np.savez(os.path.join(outdir, "dst.npz"), returns=d["returns"].numpy(), winner=d["winner"].numpy(), length=d["length"].numpy(),
+                 wins=np.array(evg.ResultGather.win_counts(full)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 96), (3, 97)])
+def test_result_gather_to_rank_zero(tmp_path, oracle_mod, world, total):
+    """The preallocated form bench.py times (ResultGather: one gather of the packed [n, 4] rows to rank 0), with equal shards and
+    with shards that differ by one env: rank 0 holds what one process computes for all envs, the other ranks receive nothing."""
+    port = _free_port()
+    mp.spawn(_worker_dst, args=(world, port, str(tmp_path), total), nprocs=world, join=True)
+    ref = _rollout(total, 0)
+    g = np.load(os.path.join(str(tmp_path), "dst.npz"))
+    assert np.array_equal(g["winner"], ref["winner"]) and np.array_equal(g["length"], ref["length"]) and np.array_equal(g["returns"], ref["returns"])
+    w = ref["winner"]
+    assert g["wins"].tolist() == [int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum())]

@@ -1042,7 +1042,15 @@ env = evg.EvergladesVecEnv(cnt, device="cuda:0", seed=seed, env_id_base=first, a
 env.reset()
 env.rollout_random(steps, turns_per_launch=150)
 sd = env.episode_stats_device()
-g = evg.gather_episode_results(sd["returns"], sd["length"], sd["winner"], total)     # the path's one collective
+g = evg.gather_episode_results(sd["returns"], sd["length"], sd["winner"], total)     # the path's one collective (convenience form: all ranks)
+packed = env.packed_episode_results()                                                # evg_pack_episode_results: the payload bench.py gathers
+assert torch.equal(packed[:, :2], sd["returns"]) and torch.equal(packed[:, 2].to(torch.int8), sd["winner"]) and torch.equal(packed[:, 3].to(torch.int32), sd["length"])
+full = evg.ResultGather(cnt, total, "cuda:0")(packed)                                # the preallocated form: rank 0 only
+assert (full is None) == (rank != 0)
+if rank == 0:
+    d = evg.ResultGather.split(full)
+    assert torch.equal(d["winner"], g["winner"]) and torch.equal(d["length"], g["length"]) and torch.equal(d["returns"], g["returns"])
+    assert evg.ResultGather.win_counts(full) == tuple(g["wins"])
 s = env.get_state()
 np.savez(os.path.join(out_dir, "rank%d.npz" % rank), first=first, cnt=cnt, groups=s["groups"], nodes=s["nodes"], health=s["health"], env=s["env"],
          obs=env.obs.cpu().numpy(), g_returns=g["returns"].cpu().numpy(), g_winner=g["winner"].cpu().numpy(), g_length=g["length"].cpu().numpy(),
