@@ -260,12 +260,21 @@ def main():
     # inside it (a single rank has nothing to exchange: its results are already where rank 0 reads them)
     barrier()
     t0 = time.perf_counter()
-    kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch)
     gathered = None
-    if world > 1:      # one pack kernel + one gather of 16 B per env to rank 0
-        gathered = gather(env.packed_episode_results(out=gather.buffer))
+    if world == 1:
+        kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch)      # HIP events around the step-kernel launches, read after the last one
+    else:
+        # nothing between the launches and the collective waits for the host: the step kernels, the pack kernel and the gather are
+        # enqueued back to back on the stream; the launches' duration is read from two stream events after the closing barrier
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        rollout(args.steps, False, args.turns_per_launch)
+        ev1.record()
+        gathered = gather(env.packed_episode_results(out=gather.buffer))     # one pack kernel + one gather of 16 B per env to rank 0
     barrier()
     dt_local = time.perf_counter() - t0
+    if world > 1:
+        kernel_ms_sum = ev0.elapsed_time(ev1)
     played += args.steps
     dt = dt_local
     per_rank = None
