@@ -987,6 +987,9 @@ def test_abi_error_paths_on_a_device(evg):
         assert lib.evg_fog_of_war(h, None, None, None) == -1 and lib.evg_sightings(h, None, None) == -1
         assert lib.evg_scripted_actions(h, 99, 0, p(obs), p(act), None) == -1 and lib.evg_scripted_actions(h, 1, 2, p(obs), p(act), None) == -1
         assert lib.evg_smart_state(h, 3, p(obs), p(obs), None) == -1
+        pk = torch.zeros((9, 4), device="cuda")
+        assert lib.evg_pack_episode_results(h, None, None) == -1 and lib.evg_pack_episode_results(None, p(pk), None) == -1
+        assert lib.evg_pack_episode_results(h, C.c_void_p(pk.data_ptr() + 4), None) == -1 and b"aligned" in lib.evg_last_error()
         ms = C.c_float()
         assert lib.evg_rollout_random(h, 0, 1, p(act), p(obs), p(rew), p(done), None, None, None, C.byref(ms), None) == -1
         assert lib.evg_rollout_policies(h, 5, 1, 77, 0, p(act), p(obs), p(rew), p(done), None, None, None, None, None) == -1
@@ -1024,6 +1027,10 @@ def test_abi_error_paths_on_a_device(evg):
         env.scripted_actions("swarm", 0, out=torch.zeros((8, 2, 7, 4), dtype=torch.int32, device="cuda")[..., ::2])   # strided view
     with pytest.raises(ValueError):
         env.step(torch.zeros((7, 2, 7, 2), dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        env.packed_episode_results(out=torch.zeros((8, 3), device="cuda"))
+    pk = env.packed_episode_results()
+    assert pk.shape == (8, 4) and float(pk[:, 2].max()) == -1.0       # EVG_WINNER_NONE: no episode finished yet
     env.close()
 
 
