@@ -70,7 +70,7 @@ def kernel_source_hash():
     counter passes under profiles/ carry the same hash, and figures from another build are not used."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc")      # the files the product kernels are compiled from
-    for f in [os.path.join(csrc, n) for n in ("evg_device.h", "evg_kernels.hip", "evg_mt.h", "evg_rng.h")] + [os.path.join(ROOT, "include", "evg.h")]:
+    for f in [os.path.join(csrc, n) for n in ("evg_device.h", "evg_kernels.hip", "evg_step4.inc", "evg_mt.h", "evg_rng.h")] + [os.path.join(ROOT, "include", "evg.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

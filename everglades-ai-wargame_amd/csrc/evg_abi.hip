@@ -76,7 +76,7 @@ struct evg_handle {
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
 #ifdef EVG_DIAG                         // diagnostic libraries only, set through evg_diag_configure (never from the environment)
     uint32_t ablate = 0;
-    int32_t lanes = 64;
+    int32_t lanes = 0;                  // diagnostic library: 0 = the product's choice of step kernel, else evg_diag_configure's
     unsigned long long* stamps = nullptr;
 #endif
 };
@@ -770,10 +770,11 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
 #ifdef EVG_DIAG
 /* Diagnostic libraries only (libevg_diag.so / libevg_stamps.so; declared in no public header).
  *   ablate          bit0 orders, bit1 combat, bit2 movement, bit4 observation write-out, bit5 state store are skipped
- *   lanes_per_wave  64 (default: 32 envs per wavefront), 32 (16 envs per wavefront + 32 helper lanes) or 4 (the four-lanes-per-env kernel)
+ *   lanes_per_wave  0 (default: what the product library launches), 64 (the two-lanes-per-env kernel at every batch size and in both
+ *                   launch forms), 32 (16 envs per wavefront + 32 helper lanes) or 4 (the four-lanes-per-env kernel in both launch forms)
  *   force_ieee_div  != 0: run the step kernel's true-division branch although the table set passed the exact-quotient check */
 int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) {
-    if (!h || (lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4)) return fail(EVG_ERR_INVALID, "diag: bad argument");
+    if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4)) return fail(EVG_ERR_INVALID, "diag: bad argument");
     EVG_ON_DEVICE(h);
     h->ablate = ablate;
     h->lanes = lanes_per_wave;

@@ -1209,9 +1209,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     STAMP_WAVE_END();
 }
 
-#ifdef EVG_DIAG
-#include "evg_step4.inc"      // the four-lanes-per-env mapping: correct, measured slower; diagnostic library only
-#endif
+#include "evg_step4.inc"      // the four-lanes-per-env mapping: what persistent launches of SMALL batches run (launch_step)
 
 #undef S
 #undef io
@@ -1456,6 +1454,33 @@ static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtyp
     return (int)hipGetLastError();
 }
 
+// Persistent launches of small batches (up to kFourLaneMaxEnvs envs = one 32-env wavefront per SIMD with the two-lane kernel): the
+// four-lanes-per-env mapping of evg_step4.inc -- 16 envs per wavefront, twice the wavefronts, 2 213 instead of 3 164 vector
+// instructions per wave-turn.  While a SIMD holds one wavefront or none, what counts is how long ONE wavefront needs for a turn,
+// not the total instruction count.  Persistent form, us per turn, two-lane / four-lane (one box, tools/ab.sh-style A/B of two
+// builds): 8 192 envs 11.0 / 8.3, 16 384 envs 11.8 / 8.3, 24 576 envs 12.1 / 10.7, 32 768 envs 12.1 / 11.3, 40 960 envs
+// 14.7 / 17.6, 49 152 envs 15.2 / 17.5 -- the two-lane kernel wins as soon as SIMDs are shared.  Same state in HBM, same
+// results (the persistent form of every small-batch test runs this kernel and is compared with the two-lane single-turn form
+// and with the oracle).
+#ifndef EVG_FOUR_LANE_MAX_ENVS
+#define EVG_FOUR_LANE_MAX_ENVS 32768      // (a build-time knob only so that the crossover can be re-measured: tools/ab.sh with two builds)
+#endif
+constexpr int kFourLaneMaxEnvs = EVG_FOUR_LANE_MAX_ENVS;
+template <typename OT>
+static void launch_step4_small_t(const DevState& S, const StepIO& io, hipStream_t s) {
+    const StepArgs args{S, io};
+    hipLaunchKernelGGL((evg_step4_kernel<OT, true, 2>), dim3((S.N + 15) / 16), dim3(WG), 0, s, args);
+}
+static int launch_step4_small(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
+    switch (obs_dtype) {
+        case EVG_OBS_F32: launch_step4_small_t<float>(S, io, s); break;
+        case EVG_OBS_F64: launch_step4_small_t<double>(S, io, s); break;
+        case EVG_OBS_I16: launch_step4_small_t<int16_t>(S, io, s); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
 #ifdef EVG_DIAG
 template <bool MULTI>
 static int launch_step4(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
@@ -1487,9 +1512,11 @@ int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream
         return (int)hipGetLastError();
     }
 #ifdef EVG_DIAG
+    if (io.lanes_per_wave == 64) return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);   // the two-lane kernel at any size
     if (io.lanes_per_wave == 4 && !S.mt_key) return multi ? launch_step4<true>(S, io, obs_dtype, s) : launch_step4<false>(S, io, obs_dtype, s);
     if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
 #endif
+    if (multi && S.N <= kFourLaneMaxEnvs) return launch_step4_small(S, io, obs_dtype, s);
     return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);
 }
 

@@ -35,7 +35,7 @@ class EvergladesVecEnv(object):
         generator seeded like np.random.seed((seed + env_id_base + e) & 0xFFFFFFFF) and consumes it in the reference's
         order, so a game replays the UNMODIFIED reference process bit for bit (validation mode, sequential draws).
         library / diag: diagnostics only -- path of a diagnostic build of the library (default: the product libevg.so) and, for
-        libevg_diag.so, dict(ablate=bits, lanes=32|64, force_ieee_div=bool) passed to its evg_diag_configure."""
+        libevg_diag.so, dict(ablate=bits, lanes=0|64|32|4, force_ieee_div=bool) passed to its evg_diag_configure."""
         torch = _torch()
         self.L = _lib.load(library)
         if not torch.cuda.is_available():
@@ -72,7 +72,7 @@ class EvergladesVecEnv(object):
         if diag:
             if not hasattr(self.L, "evg_diag_configure"):
                 raise _lib.EvgError("diag options need a diagnostic library (library=_lib.DIAG_LIB_PATH); the product library has none")
-            self._check(self.L.evg_diag_configure(h, int(diag.get("ablate", 0)), int(diag.get("lanes", 64)), int(bool(diag.get("force_ieee_div", False)))))
+            self._check(self.L.evg_diag_configure(h, int(diag.get("ablate", 0)), int(diag.get("lanes", 0)), int(bool(diag.get("force_ieee_div", False)))))
         N = self.num_envs
         with torch.cuda.device(self.device):
             self.obs = torch.zeros((N, 2, _lib.OBS_LEN), dtype=self.obs_dtype, device=self.device)

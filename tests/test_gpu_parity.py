@@ -1103,10 +1103,10 @@ def test_hip_path_sharded_over_two_processes_equals_one_handle(evg, tmp_path):
 
 
 def test_four_lanes_per_env_variant_matches_oracle(evg, oracle_mod):
-    """The four-lanes-per-env mapping of the step kernel (csrc/evg_step4.inc: 16 envs per wavefront, a side shared by two lanes)
-    was built and measured slower; it lives in the diagnostic library and must give the same results:
-    caller-supplied orders incl. negative / aliased / duplicate ids, fused random and scripted rollouts in both launch forms,
-    a partial last workgroup."""
+    """The four-lanes-per-env mapping of the step kernel (csrc/evg_step4.inc: 16 envs per wavefront, a side shared by two lanes):
+    the product launches it for persistent rollouts of small batches (faster there), the diagnostic library
+    can select it in both launch forms.  It must give the same results: caller-supplied orders incl. negative / aliased / duplicate
+    ids, fused random and scripted rollouts in both launch forms, a partial last workgroup."""
     from gen_policies import policy_actions
     D = dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=4))
     N, seed = 333, 31
@@ -1148,3 +1148,38 @@ def test_four_lanes_per_env_variant_matches_oracle(evg, oracle_mod):
     assert np.array_equal(_np(env.obs).astype(np.float64), o_obs)
     check_state(env, ora.get_state(), "scripted")
     env.close()
+
+
+def test_small_batch_persistent_rollout_equals_the_two_lane_kernel(evg, oracle_mod):
+    """What the PRODUCT library launches for a persistent rollout depends on the batch size (four lanes per env up to 32 768 envs, two
+    above).  At 4 096 envs (BASELINE config 2): the product's persistent rollout, the two-lane kernel forced through the diagnostic
+    library (lanes = 64) and the oracle end in the same state, observations, orders and episode results -- random orders and the
+    scripted bots of config 5."""
+    N, seed, steps = 4096, 77, 210
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    ora.reset()
+    for t in range(steps):
+        a = ora.random_actions()
+        o_obs, _, _, _ = ora.step(a)
+    for kw in (dict(), dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=64))):
+        env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **kw)
+        env.reset()
+        env.rollout_random(steps, turns_per_launch=150)
+        assert np.array_equal(_np(env._actions), a), kw
+        _compare_whole_batch(env, ora, o_obs, ("random", tuple(kw)))
+        env.close()
+    seats = ("cycle_rush_turn25", "swarm")
+    pid = [evg.EvergladesVecEnv.POLICIES[s] for s in seats]
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    o_obs = ora.reset()
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(steps):
+        ora.scripted_actions(pid[0], 0, o_obs, oa)
+        ora.scripted_actions(pid[1], 1, o_obs, oa)
+        o_obs, _, _, _ = ora.step(oa)
+    for kw in (dict(), dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=64))):
+        env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **kw)
+        env.reset()
+        env.rollout_policies(steps, seats[0], seats[1], fused=True, turns_per_launch=150)
+        _compare_whole_batch(env, ora, o_obs, ("scripted", tuple(kw)))
+        env.close()
