@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--workload", default="random", choices=["random", "scripted"],
                     help="random: BASELINE metric config (random vs random); scripted: BASELINE config 5 (cycle_rush_turn25 vs swarm)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--rehearse-distributed", action="store_true", help="diagnostics only: run the N > 1 code path (process group, pack + gather, per-rank times) with a ONE-rank group on one GPU")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
     ap.add_argument("--diag-lanes", type=int, default=0, help="diagnostics only: kernel variant of libevg_diag.so (evg_diag_configure lanes)")
     args = ap.parse_args()
@@ -210,8 +211,12 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()      # one rank per GPU; wraps only in single-GPU rehearsals
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    dist_on = world > 1 or args.rehearse_distributed          # the N > 1 code path (a one-rank group is a rehearsal only)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -223,9 +228,13 @@ def main():
     first, cnt = evg.shard_range(total, world, rank)
     assert cnt == n_local
 
-    def barrier():
-        torch.cuda.synchronize(device)
-        if world > 1:
+    def barrier(closing=False):
+        """barrier + torch.cuda.synchronize().  The closing bracket of the timed region enqueues the barrier's collective right
+        behind the work already on the stream (RCCL orders it after the stream's events) and synchronises once, instead of waking the
+        host twice; the opening bracket drains the device first so that every rank enters the barrier idle."""
+        if not (closing and dist_on and args.backend == "nccl"):
+            torch.cuda.synchronize(device)
+        if dist_on:
             dist.barrier(device_ids=[dev_index]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -249,8 +258,8 @@ def main():
 
     env, rollout = make_env(args.obs_dtype)
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
-    gather = evg.ResultGather(n_local, total, device)          # preallocated buffers; rank 0 receives (one RCCL gather)
-    if world > 1:      # first use opens the RCCL channels: not part of the timed region
+    gather = evg.ResultGather(n_local, total, device, force=dist_on)   # preallocated buffers; rank 0 receives (one RCCL gather)
+    if dist_on:      # first use opens the RCCL channels: not part of the timed region
         gather(env.packed_episode_results(out=gather.buffer))
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch)
@@ -261,7 +270,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     gathered = None
-    if world == 1:
+    if not dist_on:
         kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch)      # HIP events around the step-kernel launches, read after the last one
     else:
         # nothing between the launches and the collective waits for the host: the step kernels, the pack kernel and the gather are
@@ -271,14 +280,14 @@ def main():
         rollout(args.steps, False, args.turns_per_launch)
         ev1.record()
         gathered = gather(env.packed_episode_results(out=gather.buffer))     # one pack kernel + one gather of 16 B per env to rank 0
-    barrier()
+    barrier(closing=True)
     dt_local = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         kernel_ms_sum = ev0.elapsed_time(ev1)
     played += args.steps
     dt = dt_local
     per_rank = None
-    if world > 1:
+    if dist_on:
         mine = torch.tensor([dt_local, kernel_ms_sum / args.steps], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -287,7 +296,7 @@ def main():
         dt = max(p["seconds"] for p in per_rank)
     step_kernel_ms = kernel_ms_sum / args.steps
     st = env.episode_stats()
-    if world == 1:
+    if not dist_on:
         gathered = gather(env.packed_episode_results())
     final_state = env.get_state() if (world == 1 and not args.no_cpu_baseline and args.workload == "random" and played <= 2000) else None
 
@@ -378,7 +387,7 @@ def main():
         }
         if valu:
             out["roofline_valu_issue"] = valu
-        if world > 1:
+        if dist_on:
             out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "one pack kernel + torch.distributed.gather of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather), inside the timed region",
                                   "per_rank": per_rank}
         if world == 1 and not args.no_cpu_baseline:
@@ -387,7 +396,7 @@ def main():
                 out["cpu_baseline"]["same_games_as_gpu"] = cpu_parity(args.seed, n_local, played - PHASES, st, final_state)
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

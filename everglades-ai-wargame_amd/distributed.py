@@ -70,11 +70,12 @@ class ResultGather:
         wins = ResultGather.win_counts(full)               # (p0, p1, ties, unfinished)
     """
 
-    def __init__(self, n_local, total_envs, device, group=None, dst=0):
+    def __init__(self, n_local, total_envs, device, group=None, dst=0, force=False):
         import torch
         import torch.distributed as dist
         self.group, self.dst, self.total = group, int(dst), int(total_envs)
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # force: run the collective even in a one-rank group (rehearsal of the N > 1 code path on one GPU)
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.counts = [shard_range(self.total, self.world, r)[1] for r in range(self.world)]
