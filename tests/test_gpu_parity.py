@@ -143,8 +143,19 @@ def test_obs_dtypes_agree(evg):
         a = envs[0].random_actions().clone()
         outs = [_np(e.step(a)[0]).astype(np.float64) for e in envs]
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), t
+    # the persistent form, in the three observation types: the small-batch kernel here (four lanes per env) ...
+    outs = [_np(e.rollout_random(97, turns_per_launch=150)[0]).astype(np.float64) for e in envs]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     for e in envs:
         e.close()
+    # ... and the two-lane kernel of large batches (a 40 000-env handle; the last 130 envs are compared)
+    big = [evg.EvergladesVecEnv(40000, seed=seed, obs_dtype=dt, auto_reset=True) for dt in ("float32", "float64", "int16")]
+    outs = []
+    for e in big:
+        e.reset()
+        outs.append(_np(e.rollout_random(97, turns_per_launch=150)[0][-130:]).astype(np.float64))
+        e.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 def test_masked_reset_and_state_roundtrip(evg, oracle_mod):
