@@ -785,6 +785,13 @@ def test_custom_tables_vs_oracle(evg, oracle_mod, force_ieee_div):
             check_state(env, ora.get_state(), tt)
             assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.sightings()), ora.sightings())
     assert env.episode_stats()["totals"][0] >= 2 * N
+    # the same table set through the persistent form (at this batch size: the four-lanes-per-env kernel)
+    env.rollout_random(120, turns_per_launch=150)
+    for tt in range(120):
+        a = ora.random_actions()
+        o_obs, _, _, _ = ora.step(a)
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs) and np.array_equal(_np(env._actions), a)
+    check_state(env, ora.get_state(), "persistent")
     env.close()
 
 
