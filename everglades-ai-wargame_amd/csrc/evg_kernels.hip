@@ -449,11 +449,16 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (MULTI) { asm volatile("" : "+s"(A)); asm volatile("" : "+v"(lane_)); T = S.T; }
     const int lane = lane_;
     if constexpr (MULTI) {
-        // The two waves of a SIMD take turns in issue priority, one turn each (hardware wave slot + turn parity): with equal
-        // priority the arbiter favours the older wave throughout, it finishes a 150-turn launch 25 % earlier and its partner then
-        // runs alone, which uses the SIMD less well than two waves do (profiles/r02_c_wave_times.txt, r02_d_*).
-        // Measured: 17.9 -> 17.2 us per turn (A/B on one box).
-        if ((__builtin_amdgcn_s_getreg(6148) + (uint32_t)iter) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        // The two waves of a SIMD share its issue slots; the arbiter goes by priority, then by age.  With equal priorities the older
+        // wave (hardware slot 0) is favoured throughout: it finishes a 150-turn launch 25 % earlier and its partner then runs alone,
+        // which uses the SIMD less well than two waves do (profiles/r02_c_wave_times.txt, r02_d_*).  Taking turns at priority 1 / 0
+        // (one turn each) removed most of that (17.9 -> 17.2 us per turn) but left the older wave 7 % ahead, because half of the time
+        // the two hold the same priority and age decides.  So no ties: the younger wave stays at 1, the older one takes 2 in three
+        // turns of five and 0 in the other two -- with 1 : 1 the younger ends 12 us ahead in a 20-turn launch, with 2 : 1 the older
+        // one does, with 3 : 2 the pair ends within 3 us of each other (tools/wave_times.py) -- 16.4 -> 16.0 us per turn (A/B on one box).
+        if (__builtin_amdgcn_s_getreg(6148) & 1u) __builtin_amdgcn_s_setprio(1);
+        else if ((0x15u >> (iter % 5)) & 1u) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
     }
     if (MULTI) PHASE(0);                                // diagnostic build: the stamps of a launch are those of its last turn
     const bool envlane = LPW == WG || lane < LPW;
