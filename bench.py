@@ -334,7 +334,8 @@ def main():
         pmc = committed_counters("pmc_traffic", n_local, args.workload, args.obs_dtype)
         sq = committed_counters("sq_counters", n_local, args.workload, args.obs_dtype)
         mand = MANDATORY_OUTPUT_BYTES[args.obs_dtype]
-        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "evg_step_kernel", "kernel_ms": step_kernel_ms,
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "evg_step4_kernel (four lanes per env: persistent launches of up to 32 768 envs)" if (tpl > 1 and n_local <= 32768) else "evg_step_kernel",
+                "kernel_ms": step_kernel_ms,
                 "kernel_ms_is": "HIP-event launch duration / turns played by the launch", "launches_timed": launches,
                 "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch, "launch_ms": launch_ms,
                 "mandatory_output_bytes_per_env_step": mand,
@@ -357,7 +358,8 @@ def main():
             # the traffic, so frac is a lower bound too); traffic stays null
             achieved = mand * n_local / (step_kernel_ms * 1e-3) / 1e9
             roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": mand,
-                         "bytes_source": "mandatory outputs only (no committed PMC pass matches kernel_source_hash %s)" % kernel_source_hash()})
+                         "bytes_source": "mandatory outputs only (profiles/ holds no PMC pass of this build, hash %s, at %d envs, workload %s, %s observations)"
+                                         % (kernel_source_hash(), n_local, args.workload, args.obs_dtype)})
         valu = None
         if sq:
             k = sq["kernels"]["persistent" if tpl > 1 else "one_launch_per_turn"]
