@@ -176,14 +176,15 @@ def test_render_is_a_warning_noop(evg):
 
 def test_product_library_has_no_diagnostic_hooks(evg):
     """The product library reads no environment variable and exports no diagnostic entry point; the kernel's ablation
-    branches, the 16-envs-per-wave variant and the forced-division switch exist only in libevg_diag.so (make diag)."""
+    branches, the helper-lane variant of the two-lane kernel (16 envs per wave, 32 idle lanes) and the forced-division switch
+    exist only in libevg_diag.so (make diag)."""
     import subprocess
     lib_path = evg._lib.LIB_PATH
     undefined = subprocess.check_output(["nm", "-D", "--undefined-only", lib_path], text=True)
     assert "getenv" not in undefined, "libevg.so must not read the environment"
     defined = subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True)
     assert "evg_diag_configure" not in defined and "evg_debug_read_stamps" not in defined
-    assert "evg_step_kernelIfLi32" not in defined                  # no 16-envs-per-wave instantiation of the step kernel
+    assert "evg_step_kernelIfLi32" not in defined                  # no helper-lane instantiation of the two-lane step kernel
     src = open(os.path.join(ROOT, "everglades-ai-wargame_amd", "_lib.py")).read() + open(os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc", "evg_abi.hip")).read()
     assert "getenv" not in src and "os.environ" not in src
     if os.path.exists(evg._lib.DIAG_LIB_PATH):
