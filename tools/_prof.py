@@ -16,11 +16,16 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def step_kernel(name, form, dtype="float"):
+OBS_CTYPE = {"float32": "float", "float64": "double", "int16": "short"}
+OBS_DTYPE = "float32"          # set by the summary scripts from their command line (the observation type of the profiled run)
+
+
+def step_kernel(name, form):
     """the step kernel of a launch form: the two-lane kernel evg_step_kernel<OT, 64, MULTI, false> or the four-lane kernel
-    evg_step4_kernel<OT, MULTI>, whichever the run used"""
+    evg_step4_kernel<OT, MULTI, WPE> (small batches), whichever the run used"""
+    dtype = OBS_CTYPE[OBS_DTYPE]
     multi = FORMS[form][0].split(",")[0]
-    return "evg_step_kernel<%s, 64, %s" % (dtype, FORMS[form][0]) in name or "evg_step4_kernel<%s, %s>" % (dtype, multi) in name
+    return "evg_step_kernel<%s, 64, %s" % (dtype, FORMS[form][0]) in name or "evg_step4_kernel<%s, %s" % (dtype, multi) in name
 
 
 def counter_rows(directory, form):

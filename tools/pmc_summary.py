@@ -14,6 +14,8 @@ tag, name = sys.argv[1], sys.argv[2]
 ENVS = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "random"
 OBS = sys.argv[5] if len(sys.argv) > 5 else "float32"
+import _prof
+_prof.OBS_DTYPE = OBS
 P = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 STATE_ROUND_TRIP = 2 * (24 * 4 + 6 * 4 + 6 * 4 + 4 + 4 + 2 * 4)      # words a launch reads at its start and writes at its end, per env (evg_device.h)
 

@@ -9,6 +9,8 @@ tag, name = sys.argv[1], sys.argv[2]
 ENVS = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "random"
 OBS = sys.argv[5] if len(sys.argv) > 5 else "float32"
+import _prof
+_prof.OBS_DTYPE = OBS
 P = os.path.join(ROOT, "gpurun_out", "sq_" + tag)
 out = {"kernel_source_hash": kernel_source_hash(), "envs": ENVS, "workload": WORKLOAD, "obs_dtype": OBS,
        "commands": {f: open(os.path.join(P, "cmd_%s.txt" % f)).read().strip() for f in FORMS if os.path.exists(os.path.join(P, "cmd_%s.txt" % f))},
