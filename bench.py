@@ -334,7 +334,7 @@ def main():
         pmc = committed_counters("pmc_traffic", n_local, args.workload, args.obs_dtype)
         sq = committed_counters("sq_counters", n_local, args.workload, args.obs_dtype)
         mand = MANDATORY_OUTPUT_BYTES[args.obs_dtype]
-        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "evg_step4_kernel (four lanes per env: persistent launches of up to 32 768 envs)" if (tpl > 1 and n_local <= 32768) else "evg_step_kernel",
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "evg_step4_kernel (four lanes per env: persistent launches of up to 49 152 envs)" if (tpl > 1 and n_local <= 49152) else "evg_step_kernel",
                 "kernel_ms": step_kernel_ms,
                 "kernel_ms_is": "HIP-event launch duration / turns played by the launch", "launches_timed": launches,
                 "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch, "launch_ms": launch_ms,

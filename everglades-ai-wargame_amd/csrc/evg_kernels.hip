@@ -1459,22 +1459,26 @@ static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtyp
     return (int)hipGetLastError();
 }
 
-// Persistent launches of small batches (up to kFourLaneMaxEnvs envs = one 32-env wavefront per SIMD with the two-lane kernel): the
-// four-lanes-per-env mapping of evg_step4.inc -- 16 envs per wavefront, twice the wavefronts, 2 213 instead of 3 164 vector
-// instructions per wave-turn.  While a SIMD holds one wavefront or none, what counts is how long ONE wavefront needs for a turn,
-// not the total instruction count.  Persistent form, us per turn, two-lane / four-lane (one box, tools/ab.sh-style A/B of two
-// builds): 8 192 envs 11.0 / 8.3, 16 384 envs 11.8 / 8.3, 24 576 envs 12.1 / 10.7, 32 768 envs 12.1 / 11.3, 40 960 envs
-// 14.7 / 17.6, 49 152 envs 15.2 / 17.5 -- the two-lane kernel wins as soon as SIMDs are shared.  Same state in HBM, same
-// results (the persistent form of every small-batch test runs this kernel and is compared with the two-lane single-turn form
-// and with the oracle).
+// Persistent launches of small and medium batches (up to kFourLaneMaxEnvs envs): the four-lanes-per-env mapping of evg_step4.inc --
+// 16 envs per wavefront, twice the wavefronts, 2 213 instead of 3 164 vector instructions per wave-turn.  While a SIMD holds few
+// wavefronts, what counts is how long ONE wavefront needs for a turn, not the total instruction count.  Persistent form, us per
+// turn, two-lane / four-lane (A/B of two builds on one box): 8 192 envs 11.0 / 8.3, 16 384 envs 11.8 / 8.3, 24 576 envs
+// 12.1 / 9.6, 32 768 envs 12.1 / 10.4 (2 048 four-lane wavefronts = two per SIMD, the 160-VGPR build at 2 waves per SIMD);
+// 40 960 envs 14.0 / 12.9, 49 152 envs 14.5 / 13.7 (up to 3 072 wavefronts = three per SIMD: the same kernel built for three,
+// still unspilled).  Beyond that the four-lane grid is no longer resident at once (4 waves per SIMD need <= 128 VGPRs: 28 spilled)
+// and the two-lane kernel wins.  Same state in HBM, same results (the persistent form of every small-batch test runs this kernel
+// and is compared with the two-lane single-turn form and with the oracle).
 #ifndef EVG_FOUR_LANE_MAX_ENVS
-#define EVG_FOUR_LANE_MAX_ENVS 32768      // (a build-time knob only so that the crossover can be re-measured: tools/ab.sh with two builds)
+#define EVG_FOUR_LANE_MAX_ENVS 49152      // (a build-time knob only so that the crossover can be re-measured: tools/ab.sh with two builds)
 #endif
 constexpr int kFourLaneMaxEnvs = EVG_FOUR_LANE_MAX_ENVS;
+constexpr int kFourLaneTwoWaveEnvs = 32768;      // up to here two wavefronts per SIMD hold the whole grid
 template <typename OT>
 static void launch_step4_small_t(const DevState& S, const StepIO& io, hipStream_t s) {
     const StepArgs args{S, io};
-    hipLaunchKernelGGL((evg_step4_kernel<OT, true, 2>), dim3((S.N + 15) / 16), dim3(WG), 0, s, args);
+    const dim3 grid((S.N + 15) / 16), block(WG);
+    if (S.N <= kFourLaneTwoWaveEnvs) hipLaunchKernelGGL((evg_step4_kernel<OT, true, 2>), grid, block, 0, s, args);
+    else hipLaunchKernelGGL((evg_step4_kernel<OT, true, 3>), grid, block, 0, s, args);
 }
 static int launch_step4_small(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
     switch (obs_dtype) {

@@ -148,8 +148,8 @@ def test_obs_dtypes_agree(evg):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     for e in envs:
         e.close()
-    # ... and the two-lane kernel of large batches (a 40 000-env handle; the last 130 envs are compared)
-    big = [evg.EvergladesVecEnv(40000, seed=seed, obs_dtype=dt, auto_reset=True) for dt in ("float32", "float64", "int16")]
+    # ... and the two-lane kernel of large batches (a 50 000-env handle; the last 130 envs are compared)
+    big = [evg.EvergladesVecEnv(50000, seed=seed, obs_dtype=dt, auto_reset=True) for dt in ("float32", "float64", "int16")]
     outs = []
     for e in big:
         e.reset()
@@ -1168,12 +1168,13 @@ def test_four_lanes_per_env_variant_matches_oracle(evg, oracle_mod):
     env.close()
 
 
-def test_small_batch_persistent_rollout_equals_the_two_lane_kernel(evg, oracle_mod):
-    """What the PRODUCT library launches for a persistent rollout depends on the batch size (four lanes per env up to 32 768 envs, two
-    above).  At 4 096 envs (BASELINE config 2): the product's persistent rollout, the two-lane kernel forced through the diagnostic
-    library (lanes = 64) and the oracle end in the same state, observations, orders and episode results -- random orders and the
-    scripted bots of config 5."""
-    N, seed, steps = 4096, 77, 210
+@pytest.mark.parametrize("N", [4096, 40960])
+def test_small_batch_persistent_rollout_equals_the_two_lane_kernel(evg, oracle_mod, N):
+    """What the PRODUCT library launches for a persistent rollout depends on the batch size (four lanes per env up to 49 152 envs --
+    built for two waves per SIMD up to 32 768 envs and for three above --, two lanes beyond).  At 4 096 envs (BASELINE config 2) and
+    at 40 960: the product's persistent rollout, the two-lane kernel forced through the diagnostic library (lanes = 64) and the
+    oracle end in the same state, observations, orders and episode results -- random orders and the scripted bots of config 5."""
+    seed, steps = 77, 210
     ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
     ora.reset()
     for t in range(steps):
