@@ -1168,7 +1168,7 @@ def test_four_lanes_per_env_variant_matches_oracle(evg, oracle_mod):
     env.close()
 
 
-@pytest.mark.parametrize("N", [4096, 40960])
+@pytest.mark.parametrize("N", [4096, 32769, 40960, 49153])       # 32 769: the first size of the three-waves build; 49 153: the first two-lane size
 def test_small_batch_persistent_rollout_equals_the_two_lane_kernel(evg, oracle_mod, N):
     """What the PRODUCT library launches for a persistent rollout depends on the batch size (four lanes per env up to 49 152 envs --
     built for two waves per SIMD up to 32 768 envs and for three above --, two lanes beyond).  At 4 096 envs (BASELINE config 2) and
