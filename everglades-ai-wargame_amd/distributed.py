@@ -87,6 +87,7 @@ class ResultGather:
         self.send = torch.zeros((self.width, 4), dtype=torch.float32, device=dev) if self.on else None
         self.recv = torch.empty((self.world, self.width, 4), dtype=torch.float32, device=dev) if (self.on and self.rank == self.dst) else None
         self.parts = list(self.recv.unbind(0)) if self.recv is not None else None
+        self.use_all_gather = False
         # where the local rows should be written to spare the copy into the send buffer (None: pass any [n_local, 4] tensor)
         self.buffer = self.send[:self.counts[self.rank]] if (self.on and not self.host) else None
 
@@ -100,7 +101,18 @@ class ResultGather:
         n = self.counts[self.rank]
         if self.buffer is None or packed.data_ptr() != self.buffer.data_ptr():
             self.send[:n].copy_(packed, non_blocking=not self.host)
-        dist.gather(self.send, self.parts, dst=self.dst, group=self.group)
+        if not self.use_all_gather:
+            try:
+                dist.gather(self.send, self.parts, dst=self.dst, group=self.group)
+            except (RuntimeError, NotImplementedError, ValueError):
+                # a backend without gather: every rank must take the same decision, and it does -- the call fails on all of them
+                # before anything is sent.  From here on the exchange is an all-gather into the same layout.
+                self.use_all_gather = True
+        if self.use_all_gather:
+            if self.recv is None:
+                self.recv = torch.empty((self.world, self.width, 4), dtype=torch.float32, device=self.send.device)
+                self.parts = list(self.recv.unbind(0))
+            dist.all_gather(self.parts, self.send, group=self.group)
         if self.rank != self.dst:
             return None
         if all(c == self.width for c in self.counts):

@@ -86,6 +86,10 @@ def _worker_dst(rank, world, port, outdir, total):
     for _ in range(2):                           # the buffers are reused from call to call
         full = g(packed)
     assert (full is None) == (rank != 0)
+    g2 = evg.ResultGather(cnt, total, "cpu", dst=0)
+    g2.use_all_gather = True                     # the fallback for a backend without gather: same result on rank 0
+    full2 = g2(packed)
+    assert (full2 is None) == (rank != 0) and (rank != 0 or torch.equal(full2, full))
     if rank == 0:
         d = evg.ResultGather.split(full)
         np.savez(os.path.join(outdir, "dst.npz"), returns=d["returns"].numpy(), winner=d["winner"].numpy(), length=d["length"].numpy(),
