@@ -70,7 +70,15 @@ class ResultGather:
         wins = ResultGather.win_counts(full)               # (p0, p1, ties, unfinished)
     """
 
-    def __init__(self, n_local, total_envs, device, group=None, dst=0, force=False):
+    # backends whose torch.distributed process group implements gather(); anything else exchanges with an all-gather
+    GATHER_BACKENDS = ("nccl", "gloo", "mpi")
+
+    def __init__(self, n_local, total_envs, device, group=None, dst=0, force=False, collective=None):
+        """collective: None = decided HERE, once, from the backend's name ("gather" for nccl (= RCCL) / gloo / mpi, "all_gather"
+        for any other backend), or "gather" / "all_gather" given by the caller -- the same on every rank, because every rank
+        sees the same backend (or passes the same argument).  __call__ never changes it and catches nothing: an error of
+        the collective propagates, so a rank with a broken communicator exits non-zero instead of parking its peers in a
+        collective that it has left."""
         import torch
         import torch.distributed as dist
         self.group, self.dst, self.total = group, int(dst), int(total_envs)
@@ -79,15 +87,24 @@ class ResultGather:
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.counts = [shard_range(self.total, self.world, r)[1] for r in range(self.world)]
-        assert self.counts[self.rank] == int(n_local), "local shard size does not match shard_range()"
+        if self.counts[self.rank] != int(n_local):
+            raise ValueError("local shard size %d does not match shard_range(%d, %d, %d) = %d" % (int(n_local), self.total, self.world, self.rank, self.counts[self.rank]))
         self.width = max(self.counts)
-        self.host = self.on and dist.get_backend(group) == "gloo"
+        self.backend = str(dist.get_backend(group)).lower() if self.on else None
+        if collective is None:
+            collective = "gather" if (self.backend in self.GATHER_BACKENDS or not self.on) else "all_gather"
+        if collective not in ("gather", "all_gather"):
+            raise ValueError("collective must be 'gather', 'all_gather' or None")
+        self.collective = collective
+        self.host = self.on and self.backend == "gloo"
         dev = torch.device("cpu") if self.host else torch.device(device)
         self.home = torch.device(device)
         self.send = torch.zeros((self.width, 4), dtype=torch.float32, device=dev) if self.on else None
-        self.recv = torch.empty((self.world, self.width, 4), dtype=torch.float32, device=dev) if (self.on and self.rank == self.dst) else None
+        # every buffer the collective touches exists before the first call (rank dst for a gather, every rank for an all-gather)
+        receives = self.on and (self.rank == self.dst or collective == "all_gather")
+        self.recv = torch.empty((self.world, self.width, 4), dtype=torch.float32, device=dev) if receives else None
         self.parts = list(self.recv.unbind(0)) if self.recv is not None else None
-        self.use_all_gather = False
+        self.calls = 0
         # where the local rows should be written to spare the copy into the send buffer (None: pass any [n_local, 4] tensor)
         self.buffer = self.send[:self.counts[self.rank]] if (self.on and not self.host) else None
 
@@ -99,20 +116,15 @@ class ResultGather:
         if not self.on:
             return packed
         n = self.counts[self.rank]
+        if tuple(packed.shape) != (n, 4):
+            raise ValueError("packed must be [%d, 4], got %s" % (n, tuple(packed.shape)))
         if self.buffer is None or packed.data_ptr() != self.buffer.data_ptr():
             self.send[:n].copy_(packed, non_blocking=not self.host)
-        if not self.use_all_gather:
-            try:
-                dist.gather(self.send, self.parts, dst=self.dst, group=self.group)
-            except (RuntimeError, NotImplementedError, ValueError):
-                # a backend without gather: every rank must take the same decision, and it does -- the call fails on all of them
-                # before anything is sent.  From here on the exchange is an all-gather into the same layout.
-                self.use_all_gather = True
-        if self.use_all_gather:
-            if self.recv is None:
-                self.recv = torch.empty((self.world, self.width, 4), dtype=torch.float32, device=self.send.device)
-                self.parts = list(self.recv.unbind(0))
+        if self.collective == "gather":
+            dist.gather(self.send, self.parts, dst=self.dst, group=self.group)
+        else:
             dist.all_gather(self.parts, self.send, group=self.group)
+        self.calls += 1
         if self.rank != self.dst:
             return None
         if all(c == self.width for c in self.counts):
@@ -120,6 +132,16 @@ class ResultGather:
         else:
             full = torch.cat([self.recv[r, :c] for r, c in enumerate(self.counts)], dim=0)
         return full.to(self.home) if self.host and self.home.type != "cpu" else full
+
+    def rows_per_rank(self, full):
+        """Rows of a gathered [total, 4] tensor that hold a finished episode (winner >= 0), per source rank: what the collective
+        actually carried from each rank (bench.py reports it for N > 1)."""
+        out, at = [], 0
+        w = full[:, 2].to("cpu")
+        for c in self.counts:
+            out.append(int((w[at:at + c] >= 0).sum()))
+            at += c
+        return out
 
     @staticmethod
     def split(full):

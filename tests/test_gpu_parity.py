@@ -1202,3 +1202,155 @@ def test_small_batch_persistent_rollout_equals_the_two_lane_kernel(evg, oracle_m
         env.rollout_policies(steps, seats[0], seats[1], fused=True, turns_per_launch=150)
         _compare_whole_batch(env, ora, o_obs, ("scripted", tuple(kw)))
         env.close()
+
+
+def test_config4_eight_shards_of_65536_vs_oracle(evg, oracle_mod):
+    """BASELINE config 4 at its full size on the HIP path: 524 288 games = 8 shards of 65 536 with global env ids r * 65 536 + e
+    (contiguous shards, global ids key the random streams), played here one shard after the other on the one GPU of the
+    box -- persistent rollout of 170 turns with auto-reset, so every env finishes an episode and starts the next.  The packed
+    16-byte result rows concatenated in rank order (what the RCCL gather delivers to rank 0), the win counts and every shard's
+    final state (groups, nodes, float64 health) and orders must equal ONE oracle run over all 524 288 envs (evaluate.py:155-160
+    win rule).  Only the transport between GPUs is not exercised here."""
+    import torch
+    R, n, seed, steps = 8, 65536, 20261004, 170
+    total = R * n
+    oracle_mod.lib().evo_set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ora = oracle_mod.Oracle(total, seed=seed, auto_reset=True)
+    ora.reset()
+    for t in range(steps):
+        a = ora.random_actions()
+        ora.step_noobs(a)
+    ost, os_ = ora.episode_stats(), ora.get_state()
+    assert (ost["length"] == 150).mean() > 0.98 and ost["totals"][0] >= total            # every env finished (at least) one episode
+    rows, totals = [], np.zeros(4, np.int64)
+    for r in range(R):
+        first, cnt = evg.shard_range(total, R, r)
+        assert (first, cnt) == (r * n, n)
+        env = evg.EvergladesVecEnv(cnt, seed=seed, env_id_base=first, auto_reset=True)
+        env.reset()
+        env.rollout_random(steps, turns_per_launch=150)
+        rows.append(env.packed_episode_results().clone())
+        st = env.episode_stats()
+        totals += st["totals"]
+        s = env.get_state()
+        sl = slice(first, first + cnt)
+        for k in ("groups", "nodes", "health", "env"):
+            assert np.array_equal(s[k], os_[k][sl]), ("shard", r, k, int((s[k] != os_[k][sl]).reshape(cnt, -1).any(axis=1).sum()), "envs differ")
+        assert np.array_equal(_np(env._actions), a[sl]), ("orders of the last turn, shard", r)
+        env.close()
+    full = _np(torch.cat(rows, dim=0))                       # [524 288, 4] in global env order: return p0, return p1, winner, length
+    assert full.shape == (total, 4)
+    assert np.array_equal(full[:, 2].astype(np.int8), ost["winner"]) and np.array_equal(full[:, 3].astype(np.int32), ost["length"])
+    assert np.allclose(full[:, :2], ost["returns"], rtol=0, atol=1e-4)
+    assert np.array_equal(totals, ost["totals"])
+    wins = evg.ResultGather.win_counts(torch.cat(rows, dim=0))
+    w = ost["winner"]
+    assert wins == (int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), 0) and sum(wins) == total
+
+
+def _melee_state(N, melee, node=6, turn=10):
+    """State arrays (evg_set_state layout): in the envs of `melee` all 24 groups stand at `node` at full health, idle, with mixed
+    arrival stamps (list order != gid order) and the node held by one of the players in part of the envs (structure defence applies to
+    that side's units, server.py:592-597); every other env is in the game_init position."""
+    groups = np.zeros((N, 2, 12, 8), np.int32)
+    nodes = np.zeros((N, 11, 2), np.int32)
+    health = np.full((N, 2, 100), 100.0)
+    env = np.zeros((N, 4), np.int32)
+    for p in range(2):
+        for k in range(12):
+            groups[:, p, k] = [1 if p == 0 else 11, -1, 0, 0, 0, 0, 8 if k < 11 else 12, 0]
+    nodes[:, :, 1] = -1
+    nodes[:, 0] = [500, 0]
+    nodes[:, 10] = [-500, 1]
+    for e in np.flatnonzero(melee):
+        for p in range(2):
+            for k in range(12):
+                groups[e, p, k, 0] = node
+                groups[e, p, k, 7] = (k * 5 + 3 * p + e) % 9          # arrival turn < `turn`
+        nodes[e, node - 1] = [[0, -1], [100, 0], [-100, 1], [37, -1]][e % 4]
+        env[e] = [turn, 0, 0, 0]
+    return groups, nodes, health, env
+
+
+def _pool_words(groups, envs_per_wave):
+    """Words of the shared damage pool every wavefront of the step kernel needs this turn (csrc/evg_kernels.hip stage 0/1: one byte
+    per alive fighting unit, rounded up to a word per side and contested node), from the evg_get_state group rows."""
+    loc, moving, cnt = groups[..., 0], groups[..., 4], groups[..., 6]
+    fight = (cnt > 0) & (moving == 0)
+    words = np.zeros(groups.shape[0], np.int64)
+    for n in range(1, 12):
+        u = (((loc == n) & fight) * cnt).sum(axis=2)                  # [N, 2] alive fighting units per side at node n
+        words += ((u[:, 0] > 0) & (u[:, 1] > 0)) * ((u[:, 0] + 3) // 4 + (u[:, 1] + 3) // 4)
+    pad = (-len(words)) % envs_per_wave
+    return np.concatenate([words, np.zeros(pad, np.int64)]).reshape(-1, envs_per_wave).sum(axis=1)
+
+
+def test_damage_pool_overflow_takes_two_passes_two_lane_kernel(evg, oracle_mod):
+    """The branch `npass == 2` of the two-lane step kernel (csrc/evg_kernels.hip: a wavefront whose fights need more than
+    DP_CAP = 1 536 pool words resolves envs 0..15 and 16..31 in two passes; reference semantics at stake: server.py:549-566,
+    573-644).  Random games never get there (armies bleed before all 200 units meet), so the position is planted: all 24 groups
+    at node 6 at full health in 64 consecutive envs = 2 x 100 units = 50 words per env = 1 600 words per wavefront.  Through
+    evg_step (single-turn form), turn by turn against the oracle; the precondition is asserted from the state before each turn."""
+    N = 96                                                   # wavefronts 0 and 1: melee; wavefront 2: ordinary openings
+    melee = np.arange(N) < 64
+    st0 = _melee_state(N, melee)
+    env = evg.EvergladesVecEnv(N, seed=99, auto_reset=False)
+    ora = oracle_mod.Oracle(N, seed=99, auto_reset=False)
+    env.reset(); ora.reset()
+    env.set_state(*st0); ora.set_state(*st0)
+    assert np.array_equal(_np(env.observe()).astype(np.float64), ora.observe())
+    two_pass_turns = 0
+    for t in range(6):
+        words = _pool_words(env.get_state()["groups"], 32)
+        if t < 2:
+            assert words[0] > 1536 and words[1] > 1536 and words[2] <= 1536, words
+        two_pass_turns += int(words[0] > 1536) + int(words[1] > 1536)
+        a = np.zeros((N, 2, 7, 2), np.int32) if t < 3 else _np(env.random_actions()).copy()    # hold (node 0 is no node), then random orders
+        obs, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(a)
+        assert np.array_equal(_np(obs).astype(np.float64), o_obs), ("obs", t)
+        assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(done), o_done)
+        check_state(env, ora.get_state(), ("two-pass combat, turn", t))
+    assert two_pass_turns >= 6
+    h = env.get_state()["health"]
+    assert (h[:64] < 100.0).mean() > 0.5                     # the melee really happened
+    env.close()
+    # the persistent instantiation of the same kernel (MULTI = true; forced through the diagnostic library at this batch size)
+    env = evg.EvergladesVecEnv(N, seed=99, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=64))
+    ora = oracle_mod.Oracle(N, seed=99, auto_reset=True)
+    env.reset(); ora.reset()
+    env.set_state(*st0); ora.set_state(*st0)
+    assert _pool_words(ora.get_state()["groups"], 32)[0] > 1536
+    env.rollout_random(3, turns_per_launch=3)                # turn 1 overflows (turn 2 no longer: the kernel-drawn orders send ~1.3 groups per side away)
+    for t in range(3):
+        a = ora.random_actions()
+        o_obs, _, _, _ = ora.step(a)
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs) and np.array_equal(_np(env._actions), a)
+    check_state(env, ora.get_state(), "two-pass combat, persistent two-lane form")
+    env.close()
+
+
+def test_damage_pool_overflow_takes_two_passes_four_lane_kernel(evg, oracle_mod):
+    """The same branch of the four-lanes-per-env kernel (csrc/evg_step4.inc: 16 envs per wavefront, DP_CAP = 640 words, passes over
+    envs 0..7 and 8..15), which the PRODUCT library runs for persistent rollouts of up to 49 152 envs: the planted melee needs
+    16 x 50 = 800 words per wavefront.  One 3-turn persistent launch with kernel-drawn random orders against the oracle; the
+    precondition of turns 1 and 2 is asserted from the oracle's states, which the final comparison ties to the device's."""
+    N = 80                                                   # wavefronts 0..2 melee, 3 ordinary, 4 mixed (half melee: 400 words, one pass)
+    melee = (np.arange(N) < 48) | ((np.arange(N) >= 64) & (np.arange(N) < 72))
+    st0 = _melee_state(N, melee)
+    env = evg.EvergladesVecEnv(N, seed=7, auto_reset=True)
+    ora = oracle_mod.Oracle(N, seed=7, auto_reset=True)
+    env.reset(); ora.reset()
+    env.set_state(*st0); ora.set_state(*st0)
+    w = _pool_words(env.get_state()["groups"], 16)
+    assert (w[:3] > 640).all() and w[3] <= 640 and 0 < w[4] <= 640, w
+    env.rollout_random(3, turns_per_launch=3)                # persistent form at N <= 49 152: evg_step4_kernel
+    for t in range(3):
+        a = ora.random_actions()
+        o_obs, _, _, _ = ora.step(a)
+        if t == 0:
+            assert (_pool_words(ora.get_state()["groups"], 16)[:3] > 640).all()       # turn 2 of the launch overflows as well
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs) and np.array_equal(_np(env._actions), a)
+    check_state(env, ora.get_state(), "two-pass combat, four-lane kernel")
+    assert (env.get_state()["health"][:48] < 100.0).mean() > 0.5
+    env.close()
