@@ -14,7 +14,7 @@ STAMPS_LIB_PATH = os.path.join(HERE, "libevg_stamps.so")  # `make -C csrc stamps
 NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105
 MAX_SCORE = 3700
 OBS_F32, OBS_F64, OBS_I16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 RNG_KEYED_PHILOX, RNG_STOCK_MT19937 = 0, 1
 POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "all_cycle", "base_rush_v1", "bull_rush",
                 "cycle_target_node", "cycle_target_node1", "cycle_target_node11", "cycle_target_node11P2", "dfs_attack", "no_action",
@@ -22,7 +22,7 @@ POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "al
 POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
 EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_fog_of_war", "evg_sightings", "evg_smart_state", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
-           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_num_envs",
+           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_launch_plan", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
 
@@ -88,6 +88,13 @@ def load(path=None):
         raise EvgError("two HIP runtimes are mapped into this process (%s): torch's stream handles and device pointers would be "
                        "invalid inside libevg.so -- rebuild libevg.so against the libamdhip64 that torch loads" % ", ".join(rts))
     vp = C.c_void_p
+    if hasattr(L, "evg_abi_version"):
+        L.evg_abi_version.restype = C.c_int
+        if L.evg_abi_version() != ABI_VERSION:
+            raise EvgError("%s: ABI version %d, binding expects %d (an older build of the library? rebuild it)" % (path, L.evg_abi_version(), ABI_VERSION))
+    missing = [n for n in EXPORTS if not hasattr(L, n)]
+    if missing:       # an older build of the library (e.g. a baseline kept for tools/ab.sh): say what it lacks instead of an AttributeError
+        raise EvgError("%s does not export %s -- it was built from older sources than this binding (ABI %d); rebuild it" % (path, ", ".join(missing), ABI_VERSION))
     L.evg_last_error.restype = C.c_char_p
     L.evg_abi_version.restype = C.c_int
     L.evg_default_tables.argtypes = [C.POINTER(EvgTables)]
@@ -116,10 +123,9 @@ def load(path=None):
     L.evg_episode_stats.argtypes = [vp, vp, vp, vp, vp]
     L.evg_episode_stats_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.evg_pack_episode_results.argtypes = [vp, vp, vp]
+    L.evg_launch_plan.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
     L.evg_num_envs.argtypes = [vp]
     L.evg_state_bytes_per_env.argtypes = [vp]
-    if L.evg_abi_version() != ABI_VERSION:
-        raise EvgError("%s: ABI version %d, binding expects %d" % (path, L.evg_abi_version(), ABI_VERSION))
     if hasattr(L, "evg_diag_configure"):      # diagnostic libraries only
         L.evg_diag_configure.argtypes = [vp, C.c_uint32, C.c_int, C.c_int]
     _libs[path] = L

@@ -72,6 +72,7 @@ struct evg_handle {
     DevTables host_tables;
     DevState S;
     DevTables* d_tables = nullptr;
+    DeviceCaps caps;                    // what the device holds at once (query_device_caps at evg_create): drives the launch plan
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
 #ifdef EVG_DIAG                         // diagnostic libraries only, set through evg_diag_configure (never from the environment)
@@ -361,6 +362,9 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     h->cfg = *cfg;
     int rc = build_dev_tables(cfg, &h->host_tables);
     if (rc != EVG_OK) { delete h; return rc; }
+    memset(&h->caps, 0, sizeof(h->caps));
+    rc = query_device_caps(cfg->device_id, cfg->obs_dtype, &h->caps);
+    if (rc) { delete h; return fail(EVG_ERR_HIP, "querying the device's capacity failed: %s", hipGetErrorString((hipError_t)rc)); }
     const size_t N = (size_t)cfg->num_envs;
     DevState& S = h->S;
     memset(&S, 0, sizeof(S));
@@ -447,7 +451,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, 0, 0, nullptr);
-    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
+    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -456,7 +460,7 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr);
-    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
+    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -560,7 +564,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         for (int l = 0; l < nlaunch; ++l) {
             io.turns = steps - done_turns < per_launch ? steps - done_turns : per_launch;
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l], s_));
-            const int rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
+            const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
             if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l + 1], s_));
             done_turns += io.turns;
@@ -577,16 +581,17 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         }
         return EVG_OK;
     }
-    // Event pairs make the queue wait for each bracketed kernel to retire, so only every 8th launch is bracketed:
-    // the sample prices the kernel, the unbracketed launches keep the stream back-to-back.
-    constexpr int kSampleEvery = 8;
-    const int nsamples = step_kernel_ms ? (steps + kSampleEvery - 1) / kSampleEvery : 0;
-    while (h->events.size() < (size_t)2 * nsamples) {
+    // One launch per turn: the loop is timed as a whole with two events on the stream (an event pair around every launch would
+    // make the queue wait for each bracketed kernel to retire and stretch what it measures): step_kernel_ms is the stream
+    // time per turn -- the step kernel, the gap to the next launch and, when the orders are not drawn by the step kernel
+    // itself (fused == 0), the action kernel(s) of the turn.  The kernel alone is in the rocprofv3 traces under profiles/.
+    while (step_kernel_ms && h->events.size() < 2) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev));
         h->events.push_back(ev);
     }
     const StepIO io = make_io(h, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? gen_mode : 0, policy0, policy1, actions_buf);
+    if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[0], s_));
     for (int i = 0; i < steps; ++i) {
         int rc = 0;
         if (fused) {
@@ -598,21 +603,15 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
             if (!rc) rc = launch_scripted_actions(h->S, policy1, 1, obs_out, actions_buf, h->cfg.obs_dtype, stream);
         }
         if (rc) return fail(EVG_ERR_HIP, "action kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        const bool sample = step_kernel_ms && i % kSampleEvery == 0;
-        if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery)], s_));
-        rc = launch_step(h->S, io, h->cfg.obs_dtype, stream);
+        rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
         if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
-        if (sample) HIP_TRY(hipEventRecord(h->events[2 * (i / kSampleEvery) + 1], s_));
     }
     if (step_kernel_ms) {
+        HIP_TRY(hipEventRecord(h->events[1], s_));
         HIP_TRY(hipStreamSynchronize(s_));
-        double tot = 0.0;
-        for (int i = 0; i < nsamples; ++i) {
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, h->events[2 * i], h->events[2 * i + 1]));
-            tot += ms;
-        }
-        *step_kernel_ms = (float)(tot / nsamples);
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->events[0], h->events[1]));
+        *step_kernel_ms = ms / (float)steps;
     }
     return EVG_OK;
 }
@@ -798,6 +797,32 @@ int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
     return EVG_OK;
 }
 #endif
+
+int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen) {
+    if (!h || !buf || buflen < 1 || turns_per_launch < 1) return fail(EVG_ERR_INVALID, "launch_plan: bad argument");
+    StepIO io = make_io(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0, nullptr);
+    io.turns = turns_per_launch;
+    const LaunchPlan p = plan_step(h->S, io, h->caps);
+    std::string s;
+    char tmp[192];
+    for (int i = 0; i < p.n; ++i) {
+        const LaunchPiece& pc = p.piece[i];
+        const int n = pc.env_hi - pc.env_lo, epw = pc.four_lane_wpe ? 16 : 32;
+        const char* kname = pc.four_lane_wpe ? "evg_step4_kernel" : "evg_step_kernel";
+#ifdef EVG_DIAG
+        if (h->lanes == 4) kname = "evg_step4_kernel";
+        if (h->lanes == 64 || h->lanes == 32) kname = "evg_step_kernel";
+#endif
+        if (h->S.mt_key) snprintf(tmp, sizeof(tmp), "%sevg_step_kernel<stock MT19937>[envs %d..%d: %d wavefronts of 32 envs]", i ? " + " : "", pc.env_lo, pc.env_hi, (n + 31) / 32);
+        else if (pc.four_lane_wpe) snprintf(tmp, sizeof(tmp), "%s%s<four lanes per env, built for %d waves per SIMD>[envs %d..%d: %d wavefronts of 16 envs]", i ? " + " : "", kname, pc.four_lane_wpe, pc.env_lo, pc.env_hi, (n + epw - 1) / epw);
+        else snprintf(tmp, sizeof(tmp), "%s%s<two lanes per env, %s>[envs %d..%d: %d wavefronts of 32 envs]", i ? " + " : "", kname, turns_per_launch > 1 ? "persistent" : "single-turn", pc.env_lo, pc.env_hi, (n + epw - 1) / epw);
+        s += tmp;
+    }
+    snprintf(tmp, sizeof(tmp), " | device: %d CUs, resident wavefronts two-lane %d, four-lane %d / %d", h->caps.cus, h->caps.slots2, h->caps.slots4_w2, h->caps.slots4_w3);
+    s += tmp;
+    snprintf(buf, (size_t)buflen, "%s", s.c_str());
+    return p.n;
+}
 
 int evg_pack_episode_results(evg_handle* h, float* out, void* stream) {
     if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");

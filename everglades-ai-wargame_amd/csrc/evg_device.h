@@ -118,6 +118,9 @@ struct StepIO {
     int32_t   policy0, policy1;
     int32_t*  actions_out;       //    ... and store them here ([N][2][7][2], may be NULL)
     int32_t   turns;             // consecutive turns per launch (> 1 only with gen_actions: the fused rollout driver)
+    int32_t   env_lo, env_hi;    // this launch plays envs [env_lo, env_hi) of the handle (workgroup b: envs env_lo + b * envs-per-wave ...);
+                                 // set by launch_step, which may split a batch into several launches (LaunchPlan)
+    int32_t   flags;             // STEP_F_*: set by launch_step from the device's capacity (DeviceCaps), not from literals
 #ifdef EVG_DIAG                  // diagnostic libraries only (libevg_diag.so, libevg_stamps.so)
     int32_t   lanes_per_wave;    // 64: 32 envs per wavefront; 32: 16 envs per wavefront + 32 helper lanes
     uint32_t  ablate;            // bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
@@ -125,8 +128,26 @@ struct StepIO {
 #endif
 };
 
+constexpr int32_t STEP_F_STAGGER = 1;      // single-turn launch whose whole grid is resident at once: the wave in hardware slot 1 of a SIMD starts late
+constexpr int32_t STEP_F_SHARED_SIMD = 2;  // four-lane kernel: more wavefronts than SIMDs, i.e. waves share a SIMD (issue priorities by hardware slot)
+
+// What the device holds at once, measured at evg_create from hipDeviceProp_t and the occupancy of the kernels themselves
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor): nothing in the launch logic assumes a 256-CU part.
+struct DeviceCaps {
+    int32_t cus;                 // compute units of the (possibly partitioned) device
+    int32_t simds;               // cus x 4
+    int32_t slots2;              // resident workgroups (= wavefronts, 32 envs each) of the two-lane step kernel: cus x 8 on MI355X (LDS-bound)
+    int32_t slots4_w2, slots4_w3;   // resident wavefronts (16 envs each) of the four-lane kernel built for 2 / 3 waves per SIMD
+};
+
+// One launch of a plan: which kernel plays which envs.
+struct LaunchPiece { int32_t four_lane_wpe; int32_t env_lo, env_hi; };      // four_lane_wpe: 0 = two-lane kernel, 2 / 3 = four-lane kernel built for that many waves per SIMD
+struct LaunchPlan { int32_t n; LaunchPiece piece[3]; };
+
 // launchers (evg_kernels.hip)
-int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream);
+int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps);
+LaunchPlan plan_step(const DevState& S, const StepIO& io, const DeviceCaps& caps);
+int launch_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps, void* stream);
 int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream);
 int launch_random_actions(const DevState& S, int32_t* actions, void* stream);
 int launch_scripted_actions(const DevState& S, int policy, int player, const void* obs, int32_t* actions, int obs_dtype, void* stream);

@@ -349,8 +349,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int lane = threadIdx.x;
     const bool envlane = LPW == WG || lane < LPW;       // owns an env side; helper lanes only join the balanced phases
     const int E = envlane ? lane >> 1 : 0, P = lane & 1;
-    const int e0 = blockIdx.x * EPW;
-    const int nvalid = min(EPW, S.N - e0);
+    const int e0 = io.env_lo + blockIdx.x * EPW;      // this launch plays envs [env_lo, env_hi) of the handle (launch_step)
+    const int nvalid = min(EPW, io.env_hi - e0);
     const bool valid = envlane && E < nvalid;
     const int e = valid ? e0 + E : e0;
     const size_t N = (size_t)S.N;
@@ -401,9 +401,9 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // cycles here, with its loads already in flight (tools/stagger.py: 35.0 -> 32.6 us per launch at 65 536 envs) ...
         {
             const uint32_t hw = __builtin_amdgcn_s_getreg(12292);                  // HW_ID[6:0]: wave_id (the wave's slot on its SIMD) [3:0], simd_id [5:4]
-            // (only while the whole grid is resident at once, i.e. up to 2 048 workgroups = 65 536 envs: a larger grid queues
-            // behind itself and its waves start at different times anyway)
-            const int nsleep = gridDim.x <= 2048u ? (int)(hw & 1u) * kStaggerSlot + (int)((hw >> 4) & 3u) * kStaggerSimd : 0;
+            // (only while the whole grid is resident at once -- STEP_F_STAGGER, set by launch_step from the device's capacity: up to
+            // 2 048 workgroups = 65 536 envs on a whole MI355X; a larger grid queues behind itself and its waves start at different times anyway)
+            const int nsleep = (io.flags & STEP_F_STAGGER) ? (int)(hw & 1u) * kStaggerSlot + (int)((hw >> 4) & 3u) * kStaggerSimd : 0;
             for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(4);
             // (issue priority for either wave of the pair makes a single-turn launch no shorter: for the late wave 32.5 -> 38.0 us,
             // for the early wave no change; A/B on one box)
@@ -1448,7 +1448,8 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
 // ---------------------------------------------------------------------------------------------
 template <int LPW, bool MULTI>
 static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
-    const dim3 grid((S.N + LPW / 2 - 1) / (LPW / 2)), block(WG);
+    const int n = io.env_hi - io.env_lo;
+    const dim3 grid((n + LPW / 2 - 1) / (LPW / 2)), block(WG);
     const StepArgs args{S, io};
     switch (obs_dtype) {
         case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, LPW, MULTI>), grid, block, 0, s, args); break;
@@ -1459,58 +1460,109 @@ static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtyp
     return (int)hipGetLastError();
 }
 
-// Persistent launches of small and medium batches (up to kFourLaneMaxEnvs envs): the four-lanes-per-env mapping of evg_step4.inc --
-// 16 envs per wavefront, twice the wavefronts, 2 213 instead of 3 164 vector instructions per wave-turn.  While a SIMD holds few
-// wavefronts, what counts is how long ONE wavefront needs for a turn, not the total instruction count.  Persistent form, us per
-// turn, two-lane / four-lane (A/B of two builds on one box): 8 192 envs 11.0 / 8.3, 16 384 envs 11.8 / 8.3, 24 576 envs
-// 12.1 / 9.6, 32 768 envs 12.1 / 10.4 (2 048 four-lane wavefronts = two per SIMD, the 160-VGPR build at 2 waves per SIMD);
-// 40 960 envs 14.0 / 12.9, 49 152 envs 14.5 / 13.7 (up to 3 072 wavefronts = three per SIMD: the same kernel built for three,
-// still unspilled).  Beyond that the four-lane grid is no longer resident at once (4 waves per SIMD need <= 128 VGPRs: 28 spilled)
-// and the two-lane kernel wins.  Same state in HBM, same results (the persistent form of every small-batch test runs this kernel
-// and is compared with the two-lane single-turn form and with the oracle).
-#ifndef EVG_FOUR_LANE_MAX_ENVS
-#define EVG_FOUR_LANE_MAX_ENVS 49152      // (a build-time knob only so that the crossover can be re-measured: tools/ab.sh with two builds)
-#endif
-constexpr int kFourLaneMaxEnvs = EVG_FOUR_LANE_MAX_ENVS;
-constexpr int kFourLaneTwoWaveEnvs = 32768;      // up to here two wavefronts per SIMD hold the whole grid
-template <typename OT>
-static void launch_step4_small_t(const DevState& S, const StepIO& io, hipStream_t s) {
+// Persistent launches of small and medium batches: the four-lanes-per-env mapping of evg_step4.inc -- 16 envs per wavefront,
+// twice the wavefronts, 2 213 instead of 3 164 vector instructions per wave-turn.  While a SIMD holds few wavefronts, what counts is
+// how long ONE wavefront needs for a turn, not the total instruction count.  Persistent form, us per turn on a whole MI355X,
+// two-lane / four-lane (A/B of two builds on one box): 8 192 envs 11.0 / 8.3, 16 384 envs 11.8 / 8.3, 24 576 envs 12.1 / 9.6,
+// 32 768 envs 12.1 / 10.4 (2 048 four-lane wavefronts = two per SIMD, the 160-VGPR build at 2 waves per SIMD); 40 960 envs
+// 14.0 / 12.9, 49 152 envs 14.5 / 13.7 (up to 3 072 wavefronts = three per SIMD: the same kernel built for three, still
+// unspilled).  Beyond that the four-lane grid is no longer resident at once (4 waves per SIMD need <= 128 VGPRs: 28 spilled) and
+// the two-lane kernel wins.  Same state in HBM, same results (the persistent form of every small-batch test runs this kernel and
+// is compared with the two-lane single-turn form and with the oracle).  The two thresholds are what the DEVICE holds
+// (DeviceCaps::slots4_w2 / slots4_w3 wavefronts of 16 envs), not literals.
+template <typename OT, bool MULTI, int WPE>
+static void launch_step4_t(const DevState& S, const StepIO& io, hipStream_t s) {
     const StepArgs args{S, io};
-    const dim3 grid((S.N + 15) / 16), block(WG);
-    if (S.N <= kFourLaneTwoWaveEnvs) hipLaunchKernelGGL((evg_step4_kernel<OT, true, 2>), grid, block, 0, s, args);
-    else hipLaunchKernelGGL((evg_step4_kernel<OT, true, 3>), grid, block, 0, s, args);
+    const dim3 grid((io.env_hi - io.env_lo + 15) / 16), block(WG);
+    hipLaunchKernelGGL((evg_step4_kernel<OT, MULTI, WPE>), grid, block, 0, s, args);
 }
-static int launch_step4_small(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
-    switch (obs_dtype) {
-        case EVG_OBS_F32: launch_step4_small_t<float>(S, io, s); break;
-        case EVG_OBS_F64: launch_step4_small_t<double>(S, io, s); break;
-        case EVG_OBS_I16: launch_step4_small_t<int16_t>(S, io, s); break;
-        default: return -1;
-    }
-    return (int)hipGetLastError();
-}
-
-#ifdef EVG_DIAG
-template <bool MULTI>
+template <bool MULTI, int WPE>
 static int launch_step4(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
-    const dim3 grid((S.N + 15) / 16), block(WG);
-    const StepArgs args{S, io};
     switch (obs_dtype) {
-        case EVG_OBS_F32: hipLaunchKernelGGL((evg_step4_kernel<float, MULTI>), grid, block, 0, s, args); break;
-        case EVG_OBS_F64: hipLaunchKernelGGL((evg_step4_kernel<double, MULTI>), grid, block, 0, s, args); break;
-        case EVG_OBS_I16: hipLaunchKernelGGL((evg_step4_kernel<int16_t, MULTI>), grid, block, 0, s, args); break;
+        case EVG_OBS_F32: launch_step4_t<float, MULTI, WPE>(S, io, s); break;
+        case EVG_OBS_F64: launch_step4_t<double, MULTI, WPE>(S, io, s); break;
+        case EVG_OBS_I16: launch_step4_t<int16_t, MULTI, WPE>(S, io, s); break;
         default: return -1;
     }
     return (int)hipGetLastError();
 }
-#endif
 
-int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream) {
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// What the device holds at once: compute units from hipDeviceProp_t, resident workgroups per CU from the occupancy of the kernels
+// themselves.  On a whole MI355X: 256 CUs, 8 two-lane workgroups per CU (LDS: 8 x 20 208 B of 160 KiB; 2 waves per SIMD) = 2 048
+// wavefronts = 65 536 envs; four-lane kernel 2 / 3 waves per SIMD = 2 048 / 3 072 wavefronts = 32 768 / 49 152 envs.
+template <typename OT>
+static int query_caps_t(DeviceCaps* c) {
+    int b2m = 0, b2s = 0, b4w2 = 0, b4w3 = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2m, (const void*)evg_step_kernel<OT, WG, true>, WG, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2s, (const void*)evg_step_kernel<OT, WG, false>, WG, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4w2, (const void*)evg_step4_kernel<OT, true, 2>, WG, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4w3, (const void*)evg_step4_kernel<OT, true, 3>, WG, 0);
+    if (e != hipSuccess) return (int)e;
+    const int b2 = b2m < b2s ? b2m : b2s;
+    if (b2 < 1 || b4w2 < 1 || b4w3 < 1) return (int)hipErrorLaunchOutOfResources;
+    c->slots2 = c->cus * b2;
+    // the four-lane builds aim at 2 / 3 waves per SIMD (amdgpu_waves_per_eu); the hardware may hold more of them, the plan does not use that
+    c->slots4_w2 = c->cus * (b4w2 < 8 ? b4w2 : 8);
+    c->slots4_w3 = c->cus * (b4w3 < 12 ? b4w3 : 12);
+    return 0;
+}
+
+int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return (int)e;
+    caps->cus = prop.multiProcessorCount;
+    caps->simds = 4 * caps->cus;
+    switch (obs_dtype) {
+        case EVG_OBS_F32: return query_caps_t<float>(caps);
+        case EVG_OBS_F64: return query_caps_t<double>(caps);
+        case EVG_OBS_I16: return query_caps_t<int16_t>(caps);
+        default: return -1;
+    }
+}
+
+// Which kernel plays which envs.  Single-turn launches (evg_step) and the stock-entropy mode: one launch of the two-lane kernel.
+// Persistent form: a batch up to what the device holds at once runs the four-lane kernel while its grid is resident at two or
+// three waves per SIMD and the two-lane kernel above that (as before, with the thresholds taken from DeviceCaps).  A LARGER batch
+// used to be one launch of ceil(N / 32) workgroups: every wavefront plays all its turns, so after the last full round of resident
+// workgroups the remainder ran alone at low occupancy for a whole launch (98 304 envs: 30.9 us per turn where 1.5 x 17.0 = 25.5
+// would be proportional).  Now the whole rounds (a multiple of slots2 x 32 envs) are one two-lane launch and the REMAINDER is its
+// own launch of the kernel that suits its size, on the same stream: its wavefronts fill the machine again.
+LaunchPlan plan_step(const DevState& S, const StepIO& io, const DeviceCaps& caps) {
+    LaunchPlan p;
+    p.n = 1;
+    p.piece[0] = LaunchPiece{0, 0, S.N};
     const bool multi = io.turns > 1;
+    if (S.mt_key || !multi) return p;
+#ifdef EVG_DIAG
+    if (io.lanes_per_wave != 0) return p;          // a forced kernel variant plays the whole batch in one launch
+#endif
+#ifdef EVG_STAMPS
+    (void)caps;
+    return p;                                       // the stamp buffer is indexed by workgroup: one launch
+#else
+    const long long cap2 = 32ll * caps.slots2, cap4_2 = 16ll * caps.slots4_w2, cap4_3 = 16ll * caps.slots4_w3;
+    const long long N = S.N;
+    const long long full = (N / cap2) * cap2, rem = N - full;
+    const int wpe = rem == 0 ? 0 : (rem <= cap4_2 ? 2 : (rem <= cap4_3 ? 3 : 0));
+    if (wpe == 0) return p;                         // whole rounds only, or a remainder that the two-lane kernel plays best: one launch
+    p.n = 0;
+    if (full > 0) p.piece[p.n++] = LaunchPiece{0, 0, (int32_t)full};
+    p.piece[p.n++] = LaunchPiece{wpe, (int32_t)full, (int32_t)N};
+    return p;
+#endif
+}
+
+int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const DeviceCaps& caps, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    StepIO io = io_in;
+    const bool multi = io.turns > 1;
+    io.env_lo = 0; io.env_hi = S.N; io.flags = 0;
+    const int grid2 = (S.N + WG / 2 - 1) / (WG / 2);
+    if (!multi && grid2 <= caps.slots2) io.flags |= STEP_F_STAGGER;
     if (S.mt_key) {                       // stock-entropy mode: single-turn launches of the sequential-draw instantiation
         if (multi) return -1;
-        const dim3 grid((S.N + WG / 2 - 1) / (WG / 2)), block(WG);
+        const dim3 grid(grid2), block(WG);
         const StepArgs args{S, io};
         switch (obs_dtype) {
             case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, WG, false, true>), grid, block, 0, s, args); break;
@@ -1521,12 +1573,25 @@ int launch_step(const DevState& S, const StepIO& io, int obs_dtype, void* stream
         return (int)hipGetLastError();
     }
 #ifdef EVG_DIAG
+    if ((S.N + 15) / 16 > caps.simds) io.flags |= STEP_F_SHARED_SIMD;
     if (io.lanes_per_wave == 64) return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);   // the two-lane kernel at any size
-    if (io.lanes_per_wave == 4 && !S.mt_key) return multi ? launch_step4<true>(S, io, obs_dtype, s) : launch_step4<false>(S, io, obs_dtype, s);
+    if (io.lanes_per_wave == 4) return multi ? launch_step4<true, 4>(S, io, obs_dtype, s) : launch_step4<false, 4>(S, io, obs_dtype, s);
     if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
+    io.flags &= ~STEP_F_SHARED_SIMD;
 #endif
-    if (multi && S.N <= kFourLaneMaxEnvs) return launch_step4_small(S, io, obs_dtype, s);
-    return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);
+    if (!multi) return launch_step_variant<64, false>(S, io, obs_dtype, s);
+    const LaunchPlan plan = plan_step(S, io, caps);
+    for (int i = 0; i < plan.n; ++i) {
+        const LaunchPiece& pc = plan.piece[i];
+        io.env_lo = pc.env_lo; io.env_hi = pc.env_hi;
+        io.flags = (pc.four_lane_wpe && (pc.env_hi - pc.env_lo + 15) / 16 > caps.simds) ? STEP_F_SHARED_SIMD : 0;
+        int rc;
+        if (pc.four_lane_wpe == 2) rc = launch_step4<true, 2>(S, io, obs_dtype, s);
+        else if (pc.four_lane_wpe == 3) rc = launch_step4<true, 3>(S, io, obs_dtype, s);
+        else rc = launch_step_variant<64, true>(S, io, obs_dtype, s);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream) {

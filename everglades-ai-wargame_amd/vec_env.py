@@ -353,6 +353,15 @@ class EvergladesVecEnv(object):
         self._check(self.L.evg_pack_episode_results(self._h, self._ptr(out), self._stream()))
         return out
 
+    def launch_plan(self, turns_per_launch=150):
+        """(number of kernel launches, description) of what one rollout launch of `turns_per_launch` turns runs for this batch on
+        this device (evg_launch_plan): the step-kernel mapping per env range and the device capacity the plan was derived from."""
+        buf = C.create_string_buffer(1024)
+        n = self.L.evg_launch_plan(self._h, int(turns_per_launch), buf, len(buf))
+        if n < 0:
+            self._check(n)
+        return n, buf.value.decode("utf-8", "replace")
+
     @property
     def state_bytes_per_env(self):
         return int(self.L.evg_state_bytes_per_env(self._h))

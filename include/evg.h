@@ -15,7 +15,8 @@
  *   - all calls return 0 on success or a negative evg_status; evg_last_error() gives the text
  *     (thread-local).  No C++ exception crosses the ABI.
  *   - step/reset/random_actions ENQUEUE on the caller's hipStream_t (`stream`, may be NULL for the
- *     default stream) and return without synchronising.  One handle per device; not thread-safe.
+ *     default stream) and return without synchronising.  A handle belongs to ONE device and is not thread-safe; any
+ *     number of handles may live on a device and run concurrently on different streams (they share nothing).
  *   - there is NO CPU fallback: evg_create fails with EVG_ERR_NO_DEVICE when no gfx950 device
  *     is usable.
  *   - env e of this handle has the global id env_id_base + e; random streams are keyed by the
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EVG_ABI_VERSION 2
+#define EVG_ABI_VERSION 3      /* 3: evg_launch_plan; 2: evg_pack_episode_results and the node words of the state as u32 */
 
 /* Fixed dimensions of the reference environment (everglades_env.py:17-22). */
 #define EVG_NUM_PLAYERS 2
@@ -225,8 +226,10 @@ int evg_scripted_reset(evg_handle* h, void* stream);
  * state of a wavefront's envs stays in LDS/registers between turns; observations, rewards, actions ... are still
  * written every turn, so the buffers hold the last turn as before).  Results are identical in all three forms.
  * Outputs as in evg_step (they hold the LAST step when the call returns).  If step_kernel_ms (host
- * pointer) is not NULL the step kernel of every 8th iteration is bracketed by hipEvents on `stream`, the
- * call synchronises the stream and stores the average of those step-kernel durations in milliseconds. */
+ * pointer) is not NULL the work is bracketed by hipEvents on `stream`, the call synchronises the stream and stores the
+ * stream time per turn in milliseconds: persistent form -- the duration of each launch (or launch plan, see
+ * evg_launch_plan), summed, over the turns played; one launch per turn -- two events around the WHOLE loop over `steps`,
+ * i.e. the step kernel plus the gap to the next launch plus, with fused == 0, the action kernel of the turn. */
 int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf, void* obs_out, float* reward_out,
                        uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
                        float* step_kernel_ms, void* stream);
@@ -276,6 +279,13 @@ int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, i
  * evaluate.py:155-181 then runs on the gathered rows): out[e] = {return of player 0, return of player 1, winner, length} as
  * float32 (the small integers are exact), 16 bytes per env, written on `stream`.  out: device memory, [N][4], 16-byte aligned. */
 int evg_pack_episode_results(evg_handle* h, float* out, void* stream);
+
+/* Which step kernel(s) a rollout launch of `turns_per_launch` turns runs for this handle's batch on this device, as text in
+ * buf (for benchmark records and logs): the kernel mapping (two / four lanes per env), the env range and wavefront count of
+ * every launch of the plan, and the device capacity the plan was derived from (compute units from hipDeviceProp_t, resident
+ * wavefronts from the kernels' own occupancy -- no 256-CU literal).  turns_per_launch == 1 describes evg_step.  Returns the
+ * number of kernel launches per rollout launch (>= 1) or a negative evg_status. */
+int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen);
 
 int evg_num_envs(const evg_handle* h);
 /* bytes of persistent device state per env (for the roofline accounting in DESIGN.md) */

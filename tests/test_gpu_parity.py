@@ -1354,3 +1354,51 @@ def test_damage_pool_overflow_takes_two_passes_four_lane_kernel(evg, oracle_mod)
     check_state(env, ora.get_state(), "two-pass combat, four-lane kernel")
     assert (env.get_state()["health"][:48] < 100.0).mean() > 0.5
     env.close()
+
+
+def test_launch_plan_follows_the_device_and_split_rollouts_match_oracle(evg, oracle_mod):
+    """The kernel selection is derived from what the device holds (compute units from hipDeviceProp_t x the kernels' own occupancy;
+    evg_launch_plan reports both), not from 256-CU literals, and a persistent rollout of a batch that is not a whole number of
+    resident rounds is split: whole rounds on the two-lane kernel, the remainder as its own launch of the kernel that suits its
+    size.  On a whole MI355X: 98 304 envs = 65 536 (two-lane) + 32 768 (four-lane, 2 waves per SIMD); 70 016 envs = 65 536 + 4 480.
+    Both against the forced single two-lane launch (diagnostic library) and the oracle, every env."""
+    import re
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    probe = evg.EvergladesVecEnv(64, seed=1)
+    n, text = probe.launch_plan(150)
+    m = re.search(r"device: (\d+) CUs, resident wavefronts two-lane (\d+), four-lane (\d+) / (\d+)", text)
+    assert n == 1 and m, text
+    d_cus, s2, s4a, s4b = (int(x) for x in m.groups())
+    assert d_cus == cus and s2 == 8 * cus and s4a == 8 * cus and s4b == 12 * cus, text       # 2 / 2 / 3 waves per SIMD
+    assert probe.launch_plan(1)[0] == 1 and "single-turn" in probe.launch_plan(1)[1]
+    probe.close()
+    cap2, cap4a, cap4b = 32 * s2, 16 * s4a, 16 * s4b
+    for N, want in ((cap4a, ["four lanes per env, built for 2"]), (cap4a + 1, ["four lanes per env, built for 3"]), (cap4b + 1, ["two lanes per env"]),
+                    (cap2, ["two lanes per env"]), (2 * cap2, ["two lanes per env"]), (cap2 + cap4a, ["two lanes per env", "four lanes per env, built for 2"]),
+                    (cap2 + cap4b, ["two lanes per env", "four lanes per env, built for 3"]), (cap2 + cap4b + 32, ["two lanes per env"])):
+        e = evg.EvergladesVecEnv(N, seed=1)
+        n, text = e.launch_plan(150)
+        parts = text.split(" | ")[0].split(" + ")
+        assert n == len(want) == len(parts) and all(w in p_ for w, p_ in zip(want, parts)), (N, text)
+        if len(want) == 2:
+            assert ("envs 0..%d:" % cap2) in parts[0] and ("envs %d..%d:" % (cap2, N)) in parts[1], (N, text)
+        else:
+            assert ("envs 0..%d:" % N) in parts[0], (N, text)
+        e.close()
+    seed, steps = 1234, 170
+    for N in (cap2 + cap4a, cap2 + 4480):
+        ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+        ora.reset()
+        for t in range(steps):
+            a = ora.random_actions()
+            o_obs, _, _, _ = ora.step(a)
+        for kw in (dict(), dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=64))):
+            env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **kw)
+            assert env.launch_plan(150)[0] == (1 if kw else 2)
+            env.reset()
+            env.rollout_random(steps, turns_per_launch=150)
+            assert np.array_equal(_np(env._actions), a), (N, kw)
+            _compare_whole_batch(env, ora, o_obs, ("split rollout", N, tuple(kw)))
+            env.close()
+        del ora
