@@ -12,7 +12,15 @@ steady state: during a 150-turn pre-roll env e is restarted at pre-roll turn pha
 (a multiplicative hash of the global env id, so neighbouring envs get unrelated phases), so afterwards the
 episode phases of the batch -- and of the 32 envs of every wavefront -- are spread uniformly over 0..149 and
 every timed turn sees the episode-average mix of early (few fights) and late (many fights) positions, with
-~1/150 of the envs resetting per turn.  A K-step timed window of any length therefore measures the same thing.
+~1/150 of the envs resetting per turn.  The MIX of positions is therefore the same for any K; the launch shape is not:
+the K timed turns are ceil(K / 150) launches of the persistent step kernel, and a launch lasts as long as its slowest
+wavefront plus a start-up and a host synchronisation, which weigh more on a 20-turn launch (--steps 20: 19-20 us per
+step) than on 150-turn ones (the default --steps 450: 16-17 us per step).  Both shapes are kept under profiles/.
+
+Besides the headline (persistent rollout form) the line carries, under config, two legs that pay one launch per turn --
+what a Gym consumer gets from env.step(): `one_launch_per_turn` (orders drawn inside the step kernel) and
+`caller_actions_per_turn` (per turn evg_random_actions into a caller tensor, then evg_step(actions): the reference's
+loop evaluate.py:143-152 with the policy's output arriving in a tensor) -- each with its own roofline object.
 
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); environments shard by
 contiguous global id (weak scaling: 65 536 per GPU) and the only collective is the gather of episode
@@ -189,6 +197,7 @@ def main():
                     help="random: BASELINE metric config (random vs random); scripted: BASELINE config 5 (cycle_rush_turn25 vs swarm)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--rehearse-distributed", action="store_true", help="diagnostics only: run the N > 1 code path (process group, pack + gather, per-rank times) with a ONE-rank group on one GPU")
+    ap.add_argument("--caller-actions", action="store_true", help="profiling runs: the MAIN leg runs the caller-supplied-actions path (per turn evg_random_actions into a tensor + evg_step); needs --turns-per-launch 1")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
     ap.add_argument("--diag-lanes", type=int, default=0, help="diagnostics only: kernel variant of libevg_diag.so (evg_diag_configure lanes)")
     args = ap.parse_args()
@@ -244,25 +253,30 @@ def main():
                                    diag=dict(lanes=args.diag_lanes) if args.diag_lanes else None)
         env.reset()
 
-        def rollout(nsteps, timed, tpl):
-            """nsteps turns through the native rollout driver (evg_rollout_random / evg_rollout_policies: launches of the step
-            kernel with the agents of both seats fused in, enqueued from C on torch's current stream).  Returns the summed
-            step-kernel time in ms (HIP events recorded on that stream around the step-kernel launches)."""
-            out = (env.rollout_random(nsteps, time_kernel=timed, turns_per_launch=tpl) if args.workload == "random" else
-                   env.rollout_policies(nsteps, "cycle_rush_turn25", "swarm", time_kernel=timed, fused=True, turns_per_launch=tpl))
+        def rollout(nsteps, timed, tpl, fused=True):
+            """nsteps turns through the native rollout driver (evg_rollout_random / evg_rollout_policies, enqueued from C on torch's
+            current stream).  fused: the step kernel draws / evaluates the orders of both seats itself; not fused (tpl must be 1):
+            per turn the action kernel(s) write the orders into a tensor and evg_step reads them -- the caller-supplied-actions path.
+            Returns the summed stream time in ms (HIP events recorded on that stream: around every persistent launch, or around the
+            whole loop of single-turn launches)."""
+            out = (env.rollout_random(nsteps, time_kernel=timed, fused=fused, turns_per_launch=tpl) if args.workload == "random" else
+                   env.rollout_policies(nsteps, "cycle_rush_turn25", "swarm", time_kernel=timed, fused=fused, turns_per_launch=tpl))
             return out[-1] * nsteps if timed else 0.0
 
         desynchronise(env, first, args.workload, rollout)
-        rollout(PHASES, True, args.turns_per_launch)          # settle: one more episode length in the launch form that is timed (also creates its timing events)
+        rollout(PHASES, True, args.turns_per_launch, main_fused)   # settle: one more episode length in the launch form that is timed (also creates its timing events)
         return env, rollout
 
+    main_fused = not args.caller_actions                      # --caller-actions (profiling runs): the main leg itself pays two launches per turn
+    if args.caller_actions and args.turns_per_launch != 1:
+        raise SystemExit("--caller-actions needs --turns-per-launch 1 (orders from a tensor exist in the single-turn form only)")
     env, rollout = make_env(args.obs_dtype)
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
     gather = evg.ResultGather(n_local, total, device, force=dist_on)   # preallocated buffers; rank 0 receives (one RCCL gather)
     if dist_on:      # first use opens the RCCL channels: not part of the timed region
         gather(env.packed_episode_results(out=gather.buffer))
     if args.warmup > 0:
-        rollout(args.warmup, True, args.turns_per_launch)
+        rollout(args.warmup, True, args.turns_per_launch, main_fused)
         played += args.warmup
 
     # ---- timed region: exactly K steps; with more than one rank the path's one collective (the gather of episode results) is
@@ -271,13 +285,13 @@ def main():
     t0 = time.perf_counter()
     gathered = None
     if not dist_on:
-        kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch)      # HIP events around the step-kernel launches, read after the last one
+        kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch, main_fused)      # HIP events around the step-kernel launches, read after the last one
     else:
         # nothing between the launches and the collective waits for the host: the step kernels, the pack kernel and the gather are
         # enqueued back to back on the stream; the launches' duration is read from two stream events after the closing barrier
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        rollout(args.steps, False, args.turns_per_launch)
+        rollout(args.steps, False, args.turns_per_launch, main_fused)
         ev1.record()
         gathered = gather(env.packed_episode_results(out=gather.buffer))     # one pack kernel + one gather of 16 B per env to rank 0
     barrier(closing=True)
@@ -302,27 +316,48 @@ def main():
 
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
     # reference's own observation dtype (float64)
-    per_turn_launch = obs_f64 = None
+    per_turn_launch = caller_leg = obs_f64 = None
     if world == 1 and not args.no_extra_legs:
-        if args.turns_per_launch > 1:
-            rollout(16, True, 1)                               # warms the single-turn instantiation and creates its events
+        def per_turn_leg(fused):
+            """150 turns, one step launch per turn, warmed; wall clock between two barriers and the stream time between two
+            events around the whole leg (so kernel_ms <= ms_per_step; the kernel alone is in profiles/*_kernel_stats.csv)"""
+            rollout(16, True, 1, fused)                        # warms the single-turn instantiation (and the action kernel) and creates the events
             barrier()
             t1 = time.perf_counter()
-            k1 = rollout(150, True, 1)
+            k1 = rollout(150, True, 1, fused)
             barrier()
             d1 = time.perf_counter() - t1
-            per_turn_launch = {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": k1 / 150,
-                               "kernel_ms_is": "mean of the step-kernel launches bracketed by HIP events (every 8th)"}
+            return {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": k1 / 150,
+                    "kernel_ms_is": "stream time per turn: two HIP events around the whole 150-turn leg / 150 (launches back to back, gaps included"
+                                    + ("" if fused else "; the action kernel of the turn included") + ")",
+                    "launches_per_turn": 1 if fused else (2 if args.workload == "random" else 3)}
+        if args.turns_per_launch > 1 or not main_fused:
+            per_turn_launch = per_turn_leg(True)
+        if main_fused:
+            caller_leg = per_turn_leg(False)
+            caller_leg["path"] = ("per turn: evg_random_actions -> caller tensor [N,2,7,2] -> evg_step(actions) (evaluate.py:143-152 with on-device agents)" if args.workload == "random" else
+                                  "per turn: evg_scripted_actions x 2 (reading the previous observations) -> caller tensor -> evg_step(actions)")
         if args.obs_dtype != "float64":
             env64, rollout64 = make_env("float64")
-            rollout64(8, True, args.turns_per_launch)
+            rollout64(8, True, args.turns_per_launch, main_fused)
             barrier()
             t1 = time.perf_counter()
-            k64 = rollout64(150, True, args.turns_per_launch)
+            k64 = rollout64(150, True, args.turns_per_launch, main_fused)
             barrier()
             d64 = time.perf_counter() - t1
             obs_f64 = {"env_steps_per_s": total * 150 / d64, "ms_per_step": d64 / 150 * 1e3, "kernel_ms": k64 / 150, "turns_per_launch": args.turns_per_launch}
             env64.close()
+
+    # ---- N > 1: what the collective carried.  Every rank counts the winners of its own rows on its device; the sum over ranks (one
+    # all-reduce of 4 integers, outside the timed region) must equal what rank 0 counts in the gathered rows.
+    dist_check = None
+    if dist_on:
+        mine_rows = env.packed_episode_results()
+        w = mine_rows[:, 2]
+        local_counts = torch.stack([(w == 0).sum(), (w == 1).sum(), (w == 2).sum(), (w < 0).sum()]).to(torch.int64)
+        summed = local_counts.clone() if args.backend == "nccl" else local_counts.cpu()
+        dist.all_reduce(summed)
+        dist_check = {"wins_p0_p1_tie_unfinished_sum_over_ranks": [int(x) for x in summed.tolist()]}
 
     if rank == 0:
         value = total * args.steps / dt
@@ -334,32 +369,65 @@ def main():
         pmc = committed_counters("pmc_traffic", n_local, args.workload, args.obs_dtype)
         sq = committed_counters("sq_counters", n_local, args.workload, args.obs_dtype)
         mand = MANDATORY_OUTPUT_BYTES[args.obs_dtype]
-        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "evg_step4_kernel (four lanes per env: persistent launches of up to 49 152 envs)" if (tpl > 1 and n_local <= 49152) else "evg_step_kernel",
-                "kernel_ms": step_kernel_ms,
-                "kernel_ms_is": "HIP-event launch duration / turns played by the launch", "launches_timed": launches,
-                "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch, "launch_ms": launch_ms,
-                "mandatory_output_bytes_per_env_step": mand,
-                "survey_8d_bytes_per_env_step": SURVEY_ALGO_BYTES_PER_ENV_STEP,
-                "survey_8d_note": "SURVEY 8(d)'s accounting (full state read + write every turn) is NOT what this kernel moves; it is reported "
-                                  "only as survey_8d_rate_GBps and never as the roofline numerator"}
-        roof["survey_8d_rate_GBps"] = SURVEY_ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9
-        if pmc:
-            form = pmc["forms"]["persistent" if tpl > 1 else "one_launch_per_turn"]
-            # steady-state bytes per env-step of the profiled launch shape; the state round trip of a launch (words read at its
-            # start, written at its end) is re-scaled to the turns per launch that were timed here
-            bpe = form["bytes_per_env_step_steady"] + form["state_round_trip_bytes_per_env"] / (args.steps / launches)
-            achieved = bpe * n_local / (step_kernel_ms * 1e-3) / 1e9
-            roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": bpe * env_steps_per_launch, "traffic_unit": "bytes per launch",
-                         "bytes_per_env_step": bpe, "bytes_source": pmc["_file"], "bytes_source_is": "rocprofv3 PMC passes of this build "
-                         "(2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction, calibrated in the same passes), per env-step, times the env-steps of the timed launches",
-                         "ratio_to_mandatory_outputs": bpe / mand, "ratio_survey_8d_to_measured": SURVEY_ALGO_BYTES_PER_ENV_STEP / bpe})
-        else:
-            # no counter pass of this build is committed: price the launches with the bytes they cannot avoid (a LOWER bound on
-            # the traffic, so frac is a lower bound too); traffic stays null
-            achieved = mand * n_local / (step_kernel_ms * 1e-3) / 1e9
-            roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": mand,
-                         "bytes_source": "mandatory outputs only (profiles/ holds no PMC pass of this build, hash %s, at %d envs, workload %s, %s observations)"
-                                         % (kernel_source_hash(), n_local, args.workload, args.obs_dtype)})
+
+        def hbm_roofline(form_key, kernel_ms, turns_per_launch_timed):
+            """roofline object of one launch form: bytes per env-step from the committed counter pass of THIS build for that form
+            (None: the unavoidable output bytes, a lower bound) x envs / the stream time per turn measured here"""
+            r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": kernel_ms, "mandatory_output_bytes_per_env_step": mand}
+            form = pmc["forms"].get(form_key) if pmc else None
+            if form:
+                # steady-state bytes per env-step of the profiled launch shape; the state round trip of a launch (words read at its
+                # start, written at its end) is re-scaled to the turns per launch that were timed here
+                bpe = form["bytes_per_env_step_steady"] + form["state_round_trip_bytes_per_env"] / turns_per_launch_timed
+                achieved = bpe * n_local / (kernel_ms * 1e-3) / 1e9
+                r.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": bpe * n_local * turns_per_launch_timed, "traffic_unit": "bytes per launch",
+                          "bytes_per_env_step": bpe, "bytes_source": pmc["_file"] + " [%s]" % form_key,
+                          "kernel_us_rocprof": form.get("kernel_us_per_turn"), "frac_at_rocprof_kernel_time": form.get("frac_of_8TBps"),
+                          "ratio_to_mandatory_outputs": bpe / mand})
+            else:
+                achieved = mand * n_local / (kernel_ms * 1e-3) / 1e9
+                r.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": mand,
+                          "bytes_source": "mandatory outputs only: a lower bound (profiles/ holds no PMC pass of this build, hash %s, for %s at %d envs, workload %s, %s observations)"
+                                          % (kernel_source_hash(), form_key, n_local, args.workload, args.obs_dtype)})
+            return r
+
+        main_form = "persistent" if tpl > 1 else ("caller_actions_per_turn" if args.caller_actions else "one_launch_per_turn")
+        roof = hbm_roofline(main_form, step_kernel_ms, args.steps / launches)
+        n_launch, plan_text = env.launch_plan(tpl)
+        roof.update({"kernel": plan_text, "kernel_launches_per_rollout_launch": n_launch, "launch_form": main_form,
+                     "kernel_ms_is": "HIP-event launch duration / turns played by the launch" if tpl > 1 else "stream time per turn (two HIP events around the timed launches)",
+                     "launches_timed": launches, "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch, "launch_ms": launch_ms,
+                     "bytes_source_is": "rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction, calibrated in the same passes), per env-step, "
+                                        "times the env-steps of the timed launches",
+                     "survey_8d_bytes_per_env_step": SURVEY_ALGO_BYTES_PER_ENV_STEP,
+                     "survey_8d_rate_GBps": SURVEY_ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9,
+                     "survey_8d_note": "SURVEY 8(d)'s accounting (full state read + write every turn) is NOT what this kernel moves; it is reported "
+                                       "only as survey_8d_rate_GBps and never as the roofline numerator"})
+        if roof.get("bytes_per_env_step"):
+            roof["ratio_survey_8d_to_measured"] = SURVEY_ALGO_BYTES_PER_ENV_STEP / roof["bytes_per_env_step"]
+        if pmc and roof["bytes_per_env_step"] < 0.5 * mand:
+            roof["note"] = ("the counters see fewer bytes than the kernel writes: the working set of this batch (%.0f MB) stays in L2 / Infinity Cache, the launch is "
+                            "latency- and issue-bound and `frac` says nothing about it" % (n_local * (1773 + 4 * 210 + 112) / 1e6))
+        # does "hbm" mean DRAM?  The counters are L2 <-> fabric requests and include Infinity-Cache (256 MiB) hits, and the 65 536-env working set
+        # (~180 MB) fits the cache: the same passes at 262 144 envs (~720 MB, far beyond it) settle it
+        big = committed_counters("pmc_traffic", 262144, args.workload, args.obs_dtype)
+        if big and pmc and n_local == 65536:
+            bm = {"envs": 262144, "working_set_MB": round(262144 * (1773 + 4 * 210 + 112) / 1e6), "source": big["_file"], "forms": {}}
+            for k in ("persistent", "one_launch_per_turn"):
+                if k in big["forms"] and k in pmc["forms"]:
+                    fb, fs = big["forms"][k], pmc["forms"][k]
+                    bm["forms"][k] = {"bytes_per_env_step": fb["bytes_per_env_step_steady"], "bytes_per_env_step_at_65536": fs["bytes_per_env_step_steady"],
+                                      "ns_per_env_step": fb["kernel_us_per_turn"] * 1e3 / 262144, "ns_per_env_step_at_65536": fs["kernel_us_per_turn"] * 1e3 / 65536,
+                                      "traffic_TBps": fb["traffic_TBps"], "frac_of_8TBps": fb["frac_of_8TBps"]}
+            pf = bm["forms"].get("persistent")
+            if pf:
+                bm["same_rate_beyond_the_infinity_cache"] = bool(abs(pf["bytes_per_env_step"] / pf["bytes_per_env_step_at_65536"] - 1) < 0.05 and
+                                                                 pf["ns_per_env_step"] / pf["ns_per_env_step_at_65536"] < 1.08)
+            roof["beyond_mall"] = bm
+        for leg, key in ((per_turn_launch, "one_launch_per_turn"), (caller_leg, "caller_actions_per_turn")):
+            if leg is not None:
+                leg["roofline"] = hbm_roofline(key, leg["kernel_ms"], 1)
+                leg["roofline"]["kernel"] = env.launch_plan(1)[1]
         valu = None
         if sq:
             k = sq["kernels"]["persistent" if tpl > 1 else "one_launch_per_turn"]
@@ -380,7 +448,8 @@ def main():
                        "window": "desynchronised steady state: 150-turn pre-roll restarts env e at pre-roll turn hash(e) mod 150 (episode phases uniform over 0..149, unrelated between neighbouring envs), "
                                  "then 150 settle turns, --warmup turns and the K timed turns",
                        "envs_per_gpu": n_local, "total_envs": total, "turns_per_launch": tpl, "turns_of_last_timed_launch": turns_last_launch,
-                       "one_launch_per_turn": per_turn_launch, "obs_float64": obs_f64, "parallelism": "env-sharded x%d" % world,
+                       "launch_form": main_form,
+                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "obs_float64": obs_f64, "parallelism": "env-sharded x%d" % world,
                        "kernel_source_hash": kernel_source_hash(),
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
@@ -390,7 +459,19 @@ def main():
         if valu:
             out["roofline_valu_issue"] = valu
         if dist_on:
-            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": "one pack kernel + torch.distributed.gather of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather), inside the timed region",
+            gw = list(evg.ResultGather.win_counts(gathered))
+            if gw != dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"]:
+                raise SystemExit("the gathered rows (wins %s) are not what the ranks hold (sum of their own counts %s): the collective did not carry the results"
+                                 % (gw, dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"]))
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+            except Exception as ex:                       # reporting only
+                ver = "unavailable (%s)" % type(ex).__name__
+            out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
+                                  "collective": "one pack kernel + torch.distributed.%s of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather), inside the timed region" % gather.collective,
+                                  "collective_calls": gather.calls, "gathered_rows": int(gathered.shape[0]), "gathered_rows_with_a_finished_episode_per_rank": gather.rows_per_rank(gathered),
+                                  "rows_expected_per_rank": gather.counts,
+                                  "gathered_wins_equal_sum_of_per_rank_counts": True, "wins_p0_p1_tie_unfinished_sum_over_ranks": dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"],
                                   "per_rank": per_rank}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed)

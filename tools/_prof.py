@@ -3,8 +3,11 @@ selecting the step-kernel dispatches of the TIMED window (the last 150 turns of 
 warm-up launches before them are not part of any reported figure)."""
 import csv, glob, hashlib, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FORMS = {"persistent": ("true, false>", 150, 1), "perturn": ("false, false>", 1, 150)}   # kernel-name tail, turns per launch, launches in the timed window
-FORM_KEY = {"persistent": "persistent", "perturn": "one_launch_per_turn"}
+FORMS = {"persistent": ("true, false>", 150, 1), "perturn": ("false, false>", 1, 150),     # kernel-name tail, turns per launch, step launches in the timed window
+         "caller": ("false, false>", 1, 150)}    # caller-supplied orders: per turn the action kernel(s) + the single-turn step kernel
+FORM_KEY = {"persistent": "persistent", "perturn": "one_launch_per_turn", "caller": "caller_actions_per_turn"}
+ACTION_KERNELS = ("evg_random_actions_kernel", "evg_scripted_actions_kernel")
+KERNELS_PER_TURN = 1            # of the caller form: set by the summary scripts (2 for random orders, 3 for two scripted agents)
 
 
 def kernel_source_hash():
@@ -25,6 +28,8 @@ def step_kernel(name, form):
     evg_step4_kernel<OT, MULTI, WPE> (small batches), whichever the run used"""
     dtype = OBS_CTYPE[OBS_DTYPE]
     multi = FORMS[form][0].split(",")[0]
+    if form == "caller" and any(k in name for k in ACTION_KERNELS):
+        return True
     return "evg_step_kernel<%s, 64, %s" % (dtype, FORMS[form][0]) in name or "evg_step4_kernel<%s, %s" % (dtype, multi) in name
 
 
@@ -45,7 +50,9 @@ def counter_rows(directory, form):
 
 
 def timed_window(rows, form):
-    return rows[-FORMS[form][2]:]
+    """the dispatches of the timed window: the last 150 turns of the run (one step launch each; in the caller form also the action
+    kernel(s) of the turn, KERNELS_PER_TURN dispatches per turn in all)"""
+    return rows[-FORMS[form][2] * (KERNELS_PER_TURN if form == "caller" else 1):]
 
 
 def trace_durations(directory, form):

@@ -16,6 +16,8 @@ WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "random"
 OBS = sys.argv[5] if len(sys.argv) > 5 else "float32"
 import _prof
 _prof.OBS_DTYPE = OBS
+_prof.KERNELS_PER_TURN = 2 if WORKLOAD == "random" else 3
+FORMS = {f: v for f, v in FORMS.items() if os.path.exists(os.path.join(ROOT, "gpurun_out", "prof_" + tag, "cmd_%s.txt" % f))}     # the forms this run profiled
 P = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 STATE_ROUND_TRIP = 2 * (24 * 4 + 6 * 4 + 6 * 4 + 4 + 4 + 2 * 4)      # words a launch reads at its start and writes at its end, per env (evg_device.h)
 
@@ -41,18 +43,23 @@ for form, (tail, tpl, nwin) in FORMS.items():
     wr, wm = counter_rows(os.path.join(P, form + "_write"), form)
     f_kb = [r["FETCH_SIZE"] for r in timed_window(fr, form)]
     w_kb = [r["WRITE_SIZE"] for r in timed_window(wr, form)]
-    per_launch = (sum(f_kb) / len(f_kb) * round(fetch_scale) + sum(w_kb) / len(w_kb) * round(write_scale)) * 1024.0
     dur = timed_window(trace_durations(os.path.join(P, form + "_stats"), form), form)
-    mean_ns = sum(dur) / len(dur)
+    kpt = _prof.KERNELS_PER_TURN if form == "caller" else 1        # dispatches per launch unit (caller form: action kernel(s) + step kernel = one turn)
+    per_launch = (sum(f_kb) / len(f_kb) * round(fetch_scale) + sum(w_kb) / len(w_kb) * round(write_scale)) * 1024.0 * kpt
+    mean_ns = sum(dur) / len(dur) * kpt
     bpe = per_launch / tpl / ENVS
     rt = STATE_ROUND_TRIP if tpl > 1 else 0          # a single-turn launch's figure already contains its round trip
-    out["forms"][FORM_KEY[form]] = {"kernel": fm[-1]["name"], "launches_in_window": len(f_kb), "turns_per_launch": tpl,
+    out["forms"][FORM_KEY[form]] = {"kernel": fm[-1]["name"], "launches_in_window": len(f_kb) // kpt, "turns_per_launch": tpl,
                                     "FETCH_SIZE_KB_mean": sum(f_kb) / len(f_kb), "WRITE_SIZE_KB_mean": sum(w_kb) / len(w_kb),
                                     "corrected_bytes_per_launch": per_launch, "corrected_bytes_per_turn": per_launch / tpl, "bytes_per_env_step": bpe,
                                     "state_round_trip_bytes_per_env": rt, "bytes_per_env_step_steady": bpe - rt / tpl,
                                     "kernel_ns_mean_timed_window": mean_ns, "kernel_us_per_turn": mean_ns / tpl / 1e3,
                                     "traffic_TBps": per_launch / mean_ns / 1e3, "frac_of_8TBps": per_launch / mean_ns / 1e3 / 8.0,
-                                    "vgpr": fm[-1]["vgpr"], "agpr": fm[-1]["agpr"], "sgpr": fm[-1]["sgpr"], "lds_bytes": fm[-1]["lds"], "scratch": fm[-1]["scratch"]}
+                                    "kernels_per_turn": kpt,
+                                    "vgpr_allocated": 2 * fm[-1]["vgpr"], "vgpr_rocprofv3_column": fm[-1]["vgpr"],
+                                    "vgpr_note": "rocprofv3's VGPR_Count column counts in units of two registers on gfx950: 92 = 184 allocated = the compiler's 181 "
+                                                 "(make resource-usage) rounded up to the allocation granule of 8; single-turn 100 = 200 allocated (198 used)",
+                                    "agpr": fm[-1]["agpr"], "sgpr": fm[-1]["sgpr"], "lds_bytes": fm[-1]["lds"], "scratch": fm[-1]["scratch"]}
     src = glob.glob(os.path.join(P, form + "_stats", "*", "*_kernel_stats.csv"))[0]
     lines = open(src).read().splitlines()
     stats_lines.append('"# %s  --  rocprofv3 --kernel-trace --stats --output-format csv -- %s"' % (FORM_KEY[form], out["commands"][form]))
