@@ -73,6 +73,9 @@ struct evg_handle {
     DevState S;
     DevTables* d_tables = nullptr;
     DeviceCaps caps;                    // what the device holds at once (query_device_caps at evg_create): drives the launch plan
+    uint32_t progress_counter = 1;      // next unused value of the chunk flags (DevState::progress), monotonic over launches
+    uint64_t last_chunked_units = 0;    // units of the last chunked launch (all XCDs) and per XCD: checked against the queues by evg_episode_stats
+    uint32_t last_chunked_units_x[16] = {0};
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
 #ifdef EVG_DIAG                         // diagnostic libraries only, set through evg_diag_configure (never from the environment)
@@ -387,6 +390,9 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (!rc) rc = dev_alloc(h, &S.agent_cycle, 2 * N);
     if (!rc) rc = dev_alloc(h, &S.agent_swarm, 2 * N);
     if (!rc) rc = dev_alloc(h, &S.agent_dfs, 2 * N);
+    if (!rc) rc = dev_alloc(h, &S.progress, (N + 31) / 32 + 1);
+    if (!rc) rc = dev_alloc(h, &S.queue, 1024);          // 16 queue counters; the create-time XCD probe borrows the rest
+    if (!rc) rc = dev_alloc(h, &S.fault, 1);
     if (!rc) rc = dev_alloc(h, &h->d_tables, 1);
     uint32_t *mt_key = nullptr, *mt_pos = nullptr;       // attached to S after the create-time reset, which must not draw
     if (!rc && cfg->rng_mode == EVG_RNG_STOCK_MT19937) {
@@ -405,6 +411,23 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (e == hipSuccess) e = hipMemset(S.fin_len, 0, N * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(S.fin_win, 0xFF, N);
     if (e == hipSuccess) e = hipMemset(S.totals, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(S.progress, 0, ((N + 31) / 32 + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(S.fault, 0, sizeof(uint32_t));
+    if (e == hipSuccess) {
+        // the XCDs of this device (8 on a whole MI355X; a partitioned device has fewer): 1 024 one-wave workgroups report their XCC id
+        std::vector<uint32_t> ids(1024, 0xFFu);
+        e = (hipError_t)launch_xcd_probe(S.queue, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(ids.data(), S.queue, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemset(S.queue, 0, 1024 * sizeof(uint32_t));
+        uint32_t seen = 0;
+        for (uint32_t v : ids) if (v < 16u) seen |= 1u << v;
+        S.xcd_rank = ~0ull;
+        S.nxcd = 0;
+        for (uint32_t x = 0; x < 16u; ++x)
+            if ((seen >> x) & 1u) { S.xcd_rank = (S.xcd_rank & ~(15ull << (4u * x))) | ((uint64_t)S.nxcd << (4u * x)); S.nxcd += 1; }
+        if (e == hipSuccess && (S.nxcd < 1 || S.nxcd > 15)) { evg_destroy(h); return fail(EVG_ERR_HIP, "XCD probe saw %d XCDs", S.nxcd); }
+    }
     // every env starts in the game_init position; the episode counter is then set to -1 so that the
     // first evg_reset opens episode 0
     // the launchers return the hipError_t of their own launch (0 = success); it is propagated as it is
@@ -451,7 +474,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, 0, 0, nullptr);
-    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
+    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -460,7 +483,7 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr);
-    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
+    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -564,8 +587,20 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         for (int l = 0; l < nlaunch; ++l) {
             io.turns = steps - done_turns < per_launch ? steps - done_turns : per_launch;
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l], s_));
-            const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
+            const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
             if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
+            {   // a chunked launch: remember how many units each XCD's queue holds (evg_episode_stats checks that all were taken)
+                const LaunchPlan pl = plan_step(h->S, io, h->caps);
+                h->last_chunked_units = 0;
+                const LaunchPiece& cp = pl.piece[pl.n - 1];          // a plan has at most one chunked piece: its last
+                if (cp.chunk_turns > 0) {
+                    const int nsets = (cp.env_hi - cp.env_lo + 31) / 32, nchunks = (io.turns + cp.chunk_turns - 1) / cp.chunk_turns;
+                    for (int x = 0; x < h->S.nxcd; ++x) {
+                        h->last_chunked_units_x[x] = (uint32_t)(((nsets - x + h->S.nxcd - 1) / h->S.nxcd) * nchunks);
+                        h->last_chunked_units += h->last_chunked_units_x[x];
+                    }
+                }
+            }
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l + 1], s_));
             done_turns += io.turns;
         }
@@ -603,7 +638,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
             if (!rc) rc = launch_scripted_actions(h->S, policy1, 1, obs_out, actions_buf, h->cfg.obs_dtype, stream);
         }
         if (rc) return fail(EVG_ERR_HIP, "action kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
+        rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
         if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
     if (step_kernel_ms) {
@@ -759,6 +794,20 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t)h->S.N;
+    uint32_t fault = 0;
+    HIP_TRY(hipMemcpy(&fault, h->S.fault, sizeof(fault), hipMemcpyDeviceToHost));
+    if (fault) return fail(EVG_ERR_HIP, "a chunked rollout launch failed to hand a set of envs on (fault word %u: 1 = gave up waiting for a predecessor chunk, 2 = a workgroup ran on an "
+                                        "XCD the create-time probe did not see): the results of this handle are not valid", fault);
+    if (h->last_chunked_units) {          // every unit of the last chunked launch was taken from its queue
+        uint32_t qa[1024], q[16];
+        HIP_TRY(hipMemcpy(qa, h->S.queue, sizeof(qa), hipMemcpyDeviceToHost));
+        for (int x = 0; x < 16; ++x) q[x] = qa[x * 64];          // one counter per 256-byte line
+
+        uint64_t taken = 0;
+        for (int x = 0; x < h->S.nxcd; ++x) taken += q[x] < h->last_chunked_units_x[x] ? q[x] : h->last_chunked_units_x[x];
+        if (taken != h->last_chunked_units) return fail(EVG_ERR_HIP, "the last chunked rollout launch played %llu of its %llu units: some XCD ran no workgroup of it",
+                                                       (unsigned long long)taken, (unsigned long long)h->last_chunked_units);
+    }
     if (returns) HIP_TRY(hipMemcpy(returns, h->S.fin_ret, 2 * N * sizeof(float), hipMemcpyDeviceToHost));
     if (length) HIP_TRY(hipMemcpy(length, h->S.fin_len, N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (winner) HIP_TRY(hipMemcpy(winner, h->S.fin_win, N, hipMemcpyDeviceToHost));
@@ -769,11 +818,12 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
 #ifdef EVG_DIAG
 /* Diagnostic libraries only (libevg_diag.so / libevg_stamps.so; declared in no public header).
  *   ablate          bit0 orders, bit1 combat, bit2 movement, bit4 observation write-out, bit5 state store are skipped
- *   lanes_per_wave  0 (default: what the product library launches), 64 (the two-lanes-per-env kernel at every batch size and in both
+ *   lanes_per_wave  0 (default: what the product library launches), 2 (experiment: persistent rollouts of a batch beyond what the device holds run the
+ *                   CHUNKED form over the whole batch, i.e. with a working set larger than the Infinity Cache), 64 (the two-lanes-per-env kernel at every batch size and in both
  *                   launch forms), 32 (16 envs per wavefront + 32 helper lanes) or 4 (the four-lanes-per-env kernel in both launch forms)
  *   force_ieee_div  != 0: run the step kernel's true-division branch although the table set passed the exact-quotient check */
 int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) {
-    if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4)) return fail(EVG_ERR_INVALID, "diag: bad argument");
+    if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4 && lanes_per_wave != 2)) return fail(EVG_ERR_INVALID, "diag: bad argument");
     EVG_ON_DEVICE(h);
     h->ablate = ablate;
     h->lanes = lanes_per_wave;
@@ -804,7 +854,7 @@ int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int bu
     io.turns = turns_per_launch;
     const LaunchPlan p = plan_step(h->S, io, h->caps);
     std::string s;
-    char tmp[192];
+    char tmp[320];
     for (int i = 0; i < p.n; ++i) {
         const LaunchPiece& pc = p.piece[i];
         const int n = pc.env_hi - pc.env_lo, epw = pc.four_lane_wpe ? 16 : 32;
@@ -815,6 +865,9 @@ int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int bu
 #endif
         if (h->S.mt_key) snprintf(tmp, sizeof(tmp), "%sevg_step_kernel<stock MT19937>[envs %d..%d: %d wavefronts of 32 envs]", i ? " + " : "", pc.env_lo, pc.env_hi, (n + 31) / 32);
         else if (pc.four_lane_wpe) snprintf(tmp, sizeof(tmp), "%s%s<four lanes per env, built for %d waves per SIMD>[envs %d..%d: %d wavefronts of 16 envs]", i ? " + " : "", kname, pc.four_lane_wpe, pc.env_lo, pc.env_hi, (n + epw - 1) / epw);
+        else if (pc.chunk_turns > 0) snprintf(tmp, sizeof(tmp), "%s%s<two lanes per env, persistent, chunked>[envs %d..%d: %d sets of 32 envs x %d chunks of %d turns, taken from %d per-XCD queues by %d workgroups]", i ? " + " : "", kname,
+                                              pc.env_lo, pc.env_hi, (n + epw - 1) / epw, (turns_per_launch + pc.chunk_turns - 1) / pc.chunk_turns, pc.chunk_turns, h->S.nxcd,
+                                              (n + epw - 1) / epw < h->caps.slots2 ? (n + epw - 1) / epw : h->caps.slots2);
         else snprintf(tmp, sizeof(tmp), "%s%s<two lanes per env, %s>[envs %d..%d: %d wavefronts of 32 envs]", i ? " + " : "", kname, turns_per_launch > 1 ? "persistent" : "single-turn", pc.env_lo, pc.env_hi, (n + epw - 1) / epw);
         s += tmp;
     }

@@ -102,6 +102,12 @@ struct DevState {
     uint32_t* mt_pos;            // [N]
     uint32_t  seed_lo, seed_hi, env_id_base;
     const DevTables* T;
+    uint32_t* progress;          // [ceil(N / 32)] chunked persistent launches: set s of 32 envs has finished chunk c of the launch with base b <=> progress[s] == b + c + 1
+    uint32_t* queue;             // [16] chunked launches: next unit of each XCD's queue (zeroed on the stream before every chunked launch)
+    uint32_t* fault;             // [1] bit 0: a wave gave up waiting for a predecessor chunk; bit 1: a workgroup ran on an XCD the create-time probe did not see
+                                 // (never expected; reported by evg_episode_stats)
+    uint64_t  xcd_rank;          // nibble x = rank of XCC id x among the XCDs of this device (15 = not seen by the probe at evg_create)
+    int32_t   nxcd;              // number of XCDs (8 on a whole MI355X)
 };
 
 struct StepIO {
@@ -121,6 +127,11 @@ struct StepIO {
     int32_t   env_lo, env_hi;    // this launch plays envs [env_lo, env_hi) of the handle (workgroup b: envs env_lo + b * envs-per-wave ...);
                                  // set by launch_step, which may split a batch into several launches (LaunchPlan)
     int32_t   flags;             // STEP_F_*: set by launch_step from the device's capacity (DeviceCaps), not from literals
+    int32_t   nsets;             // > 0: CHUNKED persistent launch of the two-lane kernel (batches beyond what the device holds at once): workgroup u
+                                 // plays chunk u / nsets (chunk_turns consecutive turns, the last one what is left of `turns`) of env set u % nsets
+    int32_t   chunk_turns;
+    int32_t   grid_slots;        // workgroups of a chunked launch (what the device holds at once)
+    uint32_t  progress_base;     // value of DevState::progress[set] that means "no chunk of this launch finished yet" (monotonic over launches)
 #ifdef EVG_DIAG                  // diagnostic libraries only (libevg_diag.so, libevg_stamps.so)
     int32_t   lanes_per_wave;    // 64: 32 envs per wavefront; 32: 16 envs per wavefront + 32 helper lanes
     uint32_t  ablate;            // bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
@@ -141,13 +152,15 @@ struct DeviceCaps {
 };
 
 // One launch of a plan: which kernel plays which envs.
-struct LaunchPiece { int32_t four_lane_wpe; int32_t env_lo, env_hi; };      // four_lane_wpe: 0 = two-lane kernel, 2 / 3 = four-lane kernel built for that many waves per SIMD
-struct LaunchPlan { int32_t n; LaunchPiece piece[3]; };
+struct LaunchPiece { int32_t four_lane_wpe; int32_t env_lo, env_hi; int32_t chunk_turns; };   // four_lane_wpe: 0 = two-lane kernel, 2 / 3 = four-lane kernel built for that
+                                                                                              // many waves per SIMD; chunk_turns > 0: chunked dispatch (two-lane kernel only)
+struct LaunchPlan { int32_t n; LaunchPiece piece[2]; };
 
 // launchers (evg_kernels.hip)
 int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps);
+int launch_xcd_probe(uint32_t* out /* device [1024] */, void* stream);
 LaunchPlan plan_step(const DevState& S, const StepIO& io, const DeviceCaps& caps);
-int launch_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps, void* stream);
+int launch_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps, uint32_t* progress_counter, void* stream);
 int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream);
 int launch_random_actions(const DevState& S, int32_t* actions, void* stream);
 int launch_scripted_actions(const DevState& S, int policy, int player, const void* obs, int32_t* actions, int obs_dtype, void* stream);

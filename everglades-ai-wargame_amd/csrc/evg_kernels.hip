@@ -337,9 +337,10 @@ typedef const StepArgs __attribute__((address_space(4))) * step_args_ptr;
 #define S (A->s_)
 #define io (A->io_)
 
-template <typename OT, int LPW, bool MULTI, bool MT = false>
+template <typename OT, int LPW, bool MULTI, bool MT = false, bool CHUNKED = false>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2))) evg_step_kernel(StepArgs) {
     static_assert(!MT || (!MULTI && LPW == WG), "the stock-entropy mode exists in the single-turn, 32-envs-per-wave form only");
+    static_assert(!CHUNKED || (MULTI && LPW == WG && !MT), "the chunked form is an instantiation of the persistent two-lane kernel");
     step_args_ptr A = (step_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int EPW = LPW / 2;                        // envs per wavefront
     constexpr int DP_CAP = CombatLds<LPW>::DP_CAP;
@@ -349,7 +350,43 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int lane = threadIdx.x;
     const bool envlane = LPW == WG || lane < LPW;       // owns an env side; helper lanes only join the balanced phases
     const int E = envlane ? lane >> 1 : 0, P = lane & 1;
-    const int e0 = io.env_lo + blockIdx.x * EPW;      // this launch plays envs [env_lo, env_hi) of the handle (launch_step)
+    // Which envs, which turns.  Plain launch: workgroup b plays all `turns` turns of envs env_lo + 32 b ...
+    // CHUNKED launch (io.nsets > 0: a persistent rollout of more envs than the device holds at once, plan_step): the grid is as many
+    // workgroups as the device holds; the rollout is cut into UNITS = (set of 32 envs) x (chunk of chunk_turns consecutive turns), and
+    // every workgroup takes units from a queue until it is empty, handing a set on to whoever takes its next chunk through HBM
+    // (DevState::progress).  Every wave slot holds useful work until the queue runs dry, where one launch of ceil(N / 32) whole-rollout
+    // workgroups left its last, partial round running alone at low occupancy for a whole launch (98 304 envs: 30.9 us per turn).
+    // Sets are OWNED BY AN XCD (set s belongs to XCD s mod nxcd; one queue per XCD, chunk-major; a workgroup serves the queue of the
+    // XCD it runs on, read from XCC_ID): the hand-over then stays inside one L2 and needs no L2 write-back / invalidate (an agent-scope
+    // release per chunk made this form 57 % SLOWER than the plain launch: 2 048 waves x buffer_wbl2 keep every L2 walking), only the
+    // store drain of the producer and the L1 invalidate of the consumer.  Nothing depends on dispatch order or on how the dispatcher
+    // places workgroups: a unit's predecessor was taken from the same queue earlier, by a workgroup that is running and waits for
+    // nothing taken later -- no cycle; every workgroup leaves when its queue is empty.
+    constexpr int QUEUE_STRIDE = 64;                           // words between the XCDs' queue counters (256 B)
+    constexpr bool CHUNKABLE = CHUNKED;                        // an instantiation of its own: the plain persistent kernel carries no unit loop
+    int q_xi = 0, q_nx = 0, q_units = 0;
+    if (CHUNKABLE && io.nsets > 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(63508) & 15u;                  // HW_REG_XCC_ID
+        q_xi = (int)((S.xcd_rank >> (4u * xcc)) & 15ull);                             // rank of this XCD among the device's (evg_create probes them); 15 = unknown
+        if (q_xi < S.nxcd) {
+            q_nx = (io.nsets - q_xi + S.nxcd - 1) / S.nxcd;                           // sets q_xi, q_xi + nxcd, ... are this XCD's
+            q_units = q_nx * ((io.turns + io.chunk_turns - 1) / io.chunk_turns);
+        } else if (threadIdx.x == 0) {
+            atomicOr(S.fault, 2u);                                                    // a workgroup on an XCD the probe did not see: never expected
+        }
+    }
+    STAMP_WAVE_BEGIN();
+    for (;;) {                                           // one pass per unit (exactly one pass in a plain launch)
+    int wg_set = (int)blockIdx.x, wg_chunk = 0;
+    if (CHUNKABLE && io.nsets > 0) {
+        int q = 0;
+        if (threadIdx.x == 0) q = (int)atomicAdd(S.queue + q_xi * QUEUE_STRIDE, 1u);        // every XCD's counter on a line of its own
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= q_units) break;
+        wg_chunk = q / q_nx;
+        wg_set = (q - wg_chunk * q_nx) * S.nxcd + q_xi;
+    }
+    const int e0 = io.env_lo + wg_set * EPW;          // this launch plays envs [env_lo, env_hi) of the handle (launch_step)
     const int nvalid = min(EPW, io.env_hi - e0);
     const bool valid = envlane && E < nvalid;
     const int e = valid ? e0 + E : e0;
@@ -357,7 +394,22 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const DevTables* T = S.T;
 
     STAMP(0);
-    STAMP_WAVE_BEGIN();
+    if (CHUNKABLE && wg_chunk > 0) {
+        // wait for the set's previous chunk (relaxed polls that bypass the L1), then ONE agent-scope acquire: it invalidates this CU's L1,
+        // which may still hold lines of this set from an earlier chunk.  The poll is bounded: a wave that gives up flags the handle
+        // (evg_episode_stats reports it) and goes on, so the grid always drains.
+        const uint32_t* flag = S.progress + (e0 >> 5);
+        const uint32_t want = io.progress_base + (uint32_t)wg_chunk;
+        int polls = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++polls > (1 << 21)) {                 // ~ 1 s
+                if (threadIdx.x == 0) atomicOr(S.fault, 1u);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
 #ifdef EVG_DIAG      // experiment knobs (tools/stagger.py): delay = slot x a + simd x b sleeps of 256 cycles, a = ablate[15:8] - 1, b = ablate[23:16]
     const int kStaggerSlot = (A->io_.ablate >> 8) & 0xFFu ? (int)((A->io_.ablate >> 8) & 0xFFu) - 1 : 20, kStaggerSimd = (int)((A->io_.ablate >> 16) & 0xFFu);
 #else
@@ -440,7 +492,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // One iteration = one turn.  evg_step runs exactly one; the fused rollout driver lets every wavefront play
     // `turns` consecutive turns of its envs with the state resident in LDS/registers: outputs are still written every
     // turn, but no wave waits for the slowest wave of the grid between turns, and nothing is re-loaded.
-    const int nturns = MULTI ? io.turns : 1;            // the single-turn instantiation has no loop at all
+    // (chunked launch: this workgroup's chunk_turns turns, the launch's last chunk what is left of io.turns)
+    const int nturns = MULTI ? ((CHUNKABLE && io.nsets > 0) ? min(io.chunk_turns, io.turns - wg_chunk * io.chunk_turns) : io.turns) : 1;   // the single-turn instantiation has no loop at all
     for (int iter = 0; iter < nturns; ++iter) {
     // Multi-turn form: the argument pointer and the lane id are made opaque once per turn, so that argument fields, table
     // entries and per-lane address arithmetic are recomputed next to their uses instead of being hoisted out of the loop
@@ -1211,6 +1264,15 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     PHASE(13);
     if (MULTI) WAVE_SYNC();                             // next turn's LDS traffic stays behind this turn's (global accesses of one wave are issued in order)
     }   // turns
+
+    if (!(CHUNKABLE && io.nsets > 0)) break;
+    // publish the chunk to the XCD's other workgroups: every store of this wave (state words, health rows, outputs) has reached the L2
+    // they share (s_waitcnt vmcnt(0); the vector L1 is write-through), then the flag.  No L2 write-back: the set never leaves this XCD.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store(S.progress + (e0 >> 5), io.progress_base + (uint32_t)wg_chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    WAVE_SYNC();                                         // the next unit's LDS traffic stays behind this one's
+    }   // units
+
     STAMP_WAVE_END();
 }
 
@@ -1449,12 +1511,26 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
 template <int LPW, bool MULTI>
 static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
     const int n = io.env_hi - io.env_lo;
-    const dim3 grid((n + LPW / 2 - 1) / (LPW / 2)), block(WG);
+    const int nsets = (n + LPW / 2 - 1) / (LPW / 2);
+    const dim3 grid((unsigned)nsets), block(WG);
     const StepArgs args{S, io};
     switch (obs_dtype) {
         case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, LPW, MULTI>), grid, block, 0, s, args); break;
         case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, LPW, MULTI>), grid, block, 0, s, args); break;
         case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, LPW, MULTI>), grid, block, 0, s, args); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+// the chunked form of the persistent two-lane kernel: as many workgroups as the device holds, each taking units from its XCD's queue
+static int launch_step_chunked(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
+    const dim3 grid((unsigned)io.grid_slots), block(WG);
+    const StepArgs args{S, io};
+    switch (obs_dtype) {
+        case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, WG, true, false, true>), grid, block, 0, s, args); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, WG, true, false, true>), grid, block, 0, s, args); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, WG, true, false, true>), grid, block, 0, s, args); break;
         default: return -1;
     }
     return (int)hipGetLastError();
@@ -1523,41 +1599,66 @@ int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps) {
 
 // Which kernel plays which envs.  Single-turn launches (evg_step) and the stock-entropy mode: one launch of the two-lane kernel.
 // Persistent form: a batch up to what the device holds at once runs the four-lane kernel while its grid is resident at two or
-// three waves per SIMD and the two-lane kernel above that (as before, with the thresholds taken from DeviceCaps).  A LARGER batch
-// used to be one launch of ceil(N / 32) workgroups: every wavefront plays all its turns, so after the last full round of resident
-// workgroups the remainder ran alone at low occupancy for a whole launch (98 304 envs: 30.9 us per turn where 1.5 x 17.0 = 25.5
-// would be proportional).  Now the whole rounds (a multiple of slots2 x 32 envs) are one two-lane launch and the REMAINDER is its
-// own launch of the kernel that suits its size, on the same stream: its wavefronts fill the machine again.
+// three waves per SIMD and the two-lane kernel above that (the thresholds are DeviceCaps, not literals).  A LARGER batch used to be
+// one launch of ceil(N / 32) workgroups, each playing all its turns: whole rounds of resident workgroups one after the other -- which
+// is good, every round's working set (171 MB at 65 536 envs) stays inside the 256 MB Infinity Cache -- but the REMAINDER behind the
+// last whole round ran alone at low occupancy for a whole launch (98 304 envs: 30.9 us per turn where 1.5 x 17.0 = 25.5 would be
+// proportional; 65 536 + 4 480 envs cost 28.0 instead of 18.0).  Now:
+//   * the whole rounds but the last: one plain launch, as before;
+//   * the last whole round TOGETHER WITH a remainder of up to kChunkMaxRemainderPct % of a round: one CHUNKED launch -- as many
+//     workgroups as the device holds, each taking units (set of 32 envs) x (chunk of kChunkTurns turns) from its XCD's queue and handing
+//     the set on through HBM (see the kernel's prologue): all slots stay busy until the queues run dry (98 304 envs: 26 us per turn,
+//     70 016: 18.0);
+//   * a larger remainder: its own plain launch behind the whole rounds (four-lane kernel up to 49 152 envs).  Chunking it too would
+//     cycle the launch through nearly two rounds' worth of envs, more than the Infinity Cache holds, and every turn then runs ~30 %
+//     slower (measured: 131 104 envs chunked 46 us per turn, plain 44; 262 144 chunked 90, plain 67).
+#ifndef EVG_CHUNK_TURNS
+#define EVG_CHUNK_TURNS 25                 // turns per chunk of a chunked launch (a build-time knob so that it can be re-measured with two builds: tools/scaling_lib.py)
+#endif
+[[maybe_unused]] constexpr int kChunkTurns = EVG_CHUNK_TURNS;
+[[maybe_unused]] constexpr int kChunkMaxRemainderPct = 60;
 LaunchPlan plan_step(const DevState& S, const StepIO& io, const DeviceCaps& caps) {
     LaunchPlan p;
     p.n = 1;
-    p.piece[0] = LaunchPiece{0, 0, S.N};
+    p.piece[0] = LaunchPiece{0, 0, S.N, 0};
+    p.piece[1] = LaunchPiece{0, 0, 0, 0};
     const bool multi = io.turns > 1;
     if (S.mt_key || !multi) return p;
+    [[maybe_unused]] const long long cap2 = 32ll * caps.slots2, cap4_2 = 16ll * caps.slots4_w2, cap4_3 = 16ll * caps.slots4_w3;
+    [[maybe_unused]] const long long N = S.N;
 #ifdef EVG_DIAG
-    if (io.lanes_per_wave != 0) return p;          // a forced kernel variant plays the whole batch in one launch
+    if (io.lanes_per_wave == 2) {                  // experiment: the chunked form over the WHOLE batch, whatever its size (a working set beyond the Infinity Cache)
+        if (N > cap2 && io.turns > kChunkTurns) p.piece[0].chunk_turns = kChunkTurns;
+        return p;
+    }
+    if (io.lanes_per_wave != 0) return p;          // a forced kernel variant plays the whole batch in one plain launch
 #endif
 #ifdef EVG_STAMPS
-    (void)caps;
-    return p;                                       // the stamp buffer is indexed by workgroup: one launch
+    return p;                                       // the stamp buffer is indexed by workgroup: one plain launch
 #else
-    const long long cap2 = 32ll * caps.slots2, cap4_2 = 16ll * caps.slots4_w2, cap4_3 = 16ll * caps.slots4_w3;
-    const long long N = S.N;
-    const long long full = (N / cap2) * cap2, rem = N - full;
-    const int wpe = rem == 0 ? 0 : (rem <= cap4_2 ? 2 : (rem <= cap4_3 ? 3 : 0));
-    if (wpe == 0) return p;                         // whole rounds only, or a remainder that the two-lane kernel plays best: one launch
-    p.n = 0;
-    if (full > 0) p.piece[p.n++] = LaunchPiece{0, 0, (int32_t)full};
-    p.piece[p.n++] = LaunchPiece{wpe, (int32_t)full, (int32_t)N};
+    if (N <= cap4_2) { p.piece[0].four_lane_wpe = 2; return p; }
+    if (N <= cap4_3) { p.piece[0].four_lane_wpe = 3; return p; }
+    if (N <= cap2) return p;
+    const long long full = N / cap2, rem = N - full * cap2;
+    if (rem == 0) return p;                         // whole rounds only: one plain launch
+    if (rem * 100 <= cap2 * kChunkMaxRemainderPct && io.turns > kChunkTurns) {
+        p.n = 0;
+        if (full >= 2) p.piece[p.n++] = LaunchPiece{0, 0, (int32_t)((full - 1) * cap2), 0};
+        p.piece[p.n++] = LaunchPiece{0, (int32_t)((full - 1) * cap2), (int32_t)N, kChunkTurns};
+        return p;
+    }
+    p.n = 2;
+    p.piece[0] = LaunchPiece{0, 0, (int32_t)(full * cap2), 0};
+    p.piece[1] = LaunchPiece{rem <= cap4_2 ? 2 : (rem <= cap4_3 ? 3 : 0), (int32_t)(full * cap2), (int32_t)N, 0};
     return p;
 #endif
 }
 
-int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const DeviceCaps& caps, void* stream) {
+int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const DeviceCaps& caps, uint32_t* progress_counter, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     StepIO io = io_in;
     const bool multi = io.turns > 1;
-    io.env_lo = 0; io.env_hi = S.N; io.flags = 0;
+    io.env_lo = 0; io.env_hi = S.N; io.flags = 0; io.nsets = 0; io.chunk_turns = 0; io.progress_base = 0; io.grid_slots = 0;
     const int grid2 = (S.N + WG / 2 - 1) / (WG / 2);
     if (!multi && grid2 <= caps.slots2) io.flags |= STEP_F_STAGGER;
     if (S.mt_key) {                       // stock-entropy mode: single-turn launches of the sequential-draw instantiation
@@ -1573,11 +1674,9 @@ int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const Dev
         return (int)hipGetLastError();
     }
 #ifdef EVG_DIAG
-    if ((S.N + 15) / 16 > caps.simds) io.flags |= STEP_F_SHARED_SIMD;
     if (io.lanes_per_wave == 64) return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);   // the two-lane kernel at any size
     if (io.lanes_per_wave == 4) return multi ? launch_step4<true, 4>(S, io, obs_dtype, s) : launch_step4<false, 4>(S, io, obs_dtype, s);
     if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
-    io.flags &= ~STEP_F_SHARED_SIMD;
 #endif
     if (!multi) return launch_step_variant<64, false>(S, io, obs_dtype, s);
     const LaunchPlan plan = plan_step(S, io, caps);
@@ -1585,13 +1684,33 @@ int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const Dev
         const LaunchPiece& pc = plan.piece[i];
         io.env_lo = pc.env_lo; io.env_hi = pc.env_hi;
         io.flags = (pc.four_lane_wpe && (pc.env_hi - pc.env_lo + 15) / 16 > caps.simds) ? STEP_F_SHARED_SIMD : 0;
+        io.nsets = 0; io.chunk_turns = 0;
+        if (pc.chunk_turns > 0 && progress_counter) {
+            io.nsets = (pc.env_hi - pc.env_lo + WG / 2 - 1) / (WG / 2);
+            io.chunk_turns = pc.chunk_turns;
+            io.progress_base = *progress_counter;
+            *progress_counter += (uint32_t)((io.turns + pc.chunk_turns - 1) / pc.chunk_turns) + 1u;     // the flags of this launch end at base + chunks
+            io.grid_slots = io.nsets < caps.slots2 ? io.nsets : caps.slots2;
+            const hipError_t me = hipMemsetAsync(S.queue, 0, 1024 * sizeof(uint32_t), s);               // every XCD's queue starts at unit 0
+            if (me != hipSuccess) return (int)me;
+        }
         int rc;
         if (pc.four_lane_wpe == 2) rc = launch_step4<true, 2>(S, io, obs_dtype, s);
         else if (pc.four_lane_wpe == 3) rc = launch_step4<true, 3>(S, io, obs_dtype, s);
+        else if (io.nsets > 0) rc = launch_step_chunked(S, io, obs_dtype, s);
         else rc = launch_step_variant<64, true>(S, io, obs_dtype, s);
         if (rc) return rc;
     }
     return 0;
+}
+
+// which XCC ids does this device have?  (evg_create: 1 024 one-wave workgroups report where they ran)
+__global__ void __launch_bounds__(WG) evg_xcd_probe_kernel(uint32_t* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(63508) & 15u;      // HW_REG_XCC_ID
+}
+int launch_xcd_probe(uint32_t* out, void* stream) {
+    hipLaunchKernelGGL(evg_xcd_probe_kernel, dim3(1024), dim3(WG), 0, reinterpret_cast<hipStream_t>(stream), out);
+    return (int)hipGetLastError();
 }
 
 int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream) {

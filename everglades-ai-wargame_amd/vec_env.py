@@ -83,7 +83,7 @@ class EvergladesVecEnv(object):
             self.status = torch.zeros((N,), dtype=torch.uint8, device=self.device)
             self._actions = torch.zeros((N, 2, _lib.NUM_ACTIONS, 2), dtype=torch.int32, device=self.device)
         # per-call fast path: raw pointers of the env's own buffers, the info dict and the raw-stream getter are cached
-        self._p = {k: C.c_void_p(getattr(self, k).data_ptr()) for k in ("obs", "reward", "done", "winner", "scores", "status")}
+        self._p = {k: C.c_void_p(getattr(self, k).data_ptr()) for k in ("obs", "reward", "done", "winner", "scores", "status", "_actions")}
         self._info = dict(winner=self.winner, scores=self.scores, status=self.status)
         self._act_shape = (N, 2, _lib.NUM_ACTIONS, 2)
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -253,10 +253,12 @@ class EvergladesVecEnv(object):
         consecutive turns per wavefront, outputs still written every turn).  Returns the outputs of
         the last turn like step(); with time_kernel=True also the average step-kernel time in ms (synchronises)."""
         ms = C.c_float(0.0)
-        self._check(self.L.evg_rollout_random(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
-                                             self._ptr(self.done), self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status),
-                                             C.byref(ms) if time_kernel else None, self._stream()))
-        out = (self.obs, self.reward, self.done, dict(winner=self.winner, scores=self.scores, status=self.status))
+        p = self._p                     # cached raw pointers of the env's own buffers: the call itself is the only host work before the launch
+        rc = self.L.evg_rollout_random(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p["_actions"], p["obs"], p["reward"],
+                                       p["done"], p["winner"], p["scores"], p["status"], C.byref(ms) if time_kernel else None, self._stream())
+        if rc:
+            self._check(rc)
+        out = (self.obs, self.reward, self.done, self._info)
         return out + (float(ms.value),) if time_kernel else out
 
     def rollout_policies(self, steps, policy0, policy1, time_kernel=False, fused=True, turns_per_launch=1):

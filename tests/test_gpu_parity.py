@@ -1356,12 +1356,15 @@ def test_damage_pool_overflow_takes_two_passes_four_lane_kernel(evg, oracle_mod)
     env.close()
 
 
-def test_launch_plan_follows_the_device_and_split_rollouts_match_oracle(evg, oracle_mod):
+def test_launch_plan_follows_the_device_and_chunked_rollouts_match_oracle(evg, oracle_mod):
     """The kernel selection is derived from what the device holds (compute units from hipDeviceProp_t x the kernels' own occupancy;
-    evg_launch_plan reports both), not from 256-CU literals, and a persistent rollout of a batch that is not a whole number of
-    resident rounds is split: whole rounds on the two-lane kernel, the remainder as its own launch of the kernel that suits its
-    size.  On a whole MI355X: 98 304 envs = 65 536 (two-lane) + 32 768 (four-lane, 2 waves per SIMD); 70 016 envs = 65 536 + 4 480.
-    Both against the forced single two-lane launch (diagnostic library) and the oracle, every env."""
+    evg_launch_plan reports both), not from 256-CU literals, and a persistent rollout of a batch BEYOND what the device holds at once is
+    planned so that no remainder runs alone at low occupancy (csrc/evg_kernels.hip, plan_step): whole rounds as a plain launch; the
+    last whole round together with a remainder of up to 60 % of a round as ONE CHUNKED launch -- as many workgroups as the device
+    holds, each taking units (set of 32 envs) x (chunk of 25 turns) from its XCD's queue and handing the set on through HBM --; a
+    larger remainder as its own launch.  On a whole MI355X: 98 304 envs = 3 072 sets x 6 chunks.  Random orders and the scripted bots
+    of config 5 (agent objects are handed on too), against the forced plain two-lane launch (diagnostic library) and the oracle,
+    every env."""
     import re
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
@@ -1374,31 +1377,51 @@ def test_launch_plan_follows_the_device_and_split_rollouts_match_oracle(evg, ora
     assert probe.launch_plan(1)[0] == 1 and "single-turn" in probe.launch_plan(1)[1]
     probe.close()
     cap2, cap4a, cap4b = 32 * s2, 16 * s4a, 16 * s4b
-    for N, want in ((cap4a, ["four lanes per env, built for 2"]), (cap4a + 1, ["four lanes per env, built for 3"]), (cap4b + 1, ["two lanes per env"]),
-                    (cap2, ["two lanes per env"]), (2 * cap2, ["two lanes per env"]), (cap2 + cap4a, ["two lanes per env", "four lanes per env, built for 2"]),
-                    (cap2 + cap4b, ["two lanes per env", "four lanes per env, built for 3"]), (cap2 + cap4b + 32, ["two lanes per env"])):
+    for N, want in ((cap4a, ["four lanes per env, built for 2"]), (cap4a + 1, ["four lanes per env, built for 3"]), (cap4b + 1, ["two lanes per env, persistent>"]),
+                    (cap2, ["two lanes per env, persistent>"]), (2 * cap2, ["two lanes per env, persistent>[envs 0..%d:" % (2 * cap2)]),
+                    (cap2 + 1, ["chunked>[envs 0..%d: %d sets of 32 envs x 6 chunks of 25 turns" % (cap2 + 1, s2 + 1)]),
+                    (cap2 + cap4a, ["chunked>[envs 0..%d: %d sets of 32 envs x 6 chunks" % (cap2 + cap4a, s2 + s4a // 2)]),
+                    (2 * cap2 + 4480, ["persistent>[envs 0..%d:" % cap2, "chunked>[envs %d..%d:" % (cap2, 2 * cap2 + 4480)]),
+                    (cap2 + cap4b, ["persistent>[envs 0..%d:" % cap2, "four lanes per env, built for 3 waves per SIMD>[envs %d..%d:" % (cap2, cap2 + cap4b)])):
         e = evg.EvergladesVecEnv(N, seed=1)
         n, text = e.launch_plan(150)
         parts = text.split(" | ")[0].split(" + ")
         assert n == len(want) == len(parts) and all(w in p_ for w, p_ in zip(want, parts)), (N, text)
-        if len(want) == 2:
-            assert ("envs 0..%d:" % cap2) in parts[0] and ("envs %d..%d:" % (cap2, N)) in parts[1], (N, text)
-        else:
-            assert ("envs 0..%d:" % N) in parts[0], (N, text)
+        assert "chunked" not in e.launch_plan(25)[1] and "chunked" not in e.launch_plan(1)[1]      # nothing to hand on in a launch of one chunk
         e.close()
-    seed, steps = 1234, 170
-    for N in (cap2 + cap4a, cap2 + 4480):
+    seed, steps = 1234, 195                                  # 150-turn launch (6 chunks) + 45-turn launch (2 chunks: 25 + 20)
+    for N in (cap2 + cap4a, cap2 + 4480 + 7, 2 * cap2 + 4480, cap2 + cap4b):
         ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
         ora.reset()
         for t in range(steps):
             a = ora.random_actions()
             o_obs, _, _, _ = ora.step(a)
         for kw in (dict(), dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=64))):
+            if kw and N > cap2 + cap4a:
+                continue                                     # the forced plain launch is compared at the first two sizes
             env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **kw)
-            assert env.launch_plan(150)[0] == (1 if kw else 2)
+            assert ("chunked" in env.launch_plan(150)[1]) == (not kw and N != cap2 + cap4b)
             env.reset()
             env.rollout_random(steps, turns_per_launch=150)
             assert np.array_equal(_np(env._actions), a), (N, kw)
-            _compare_whole_batch(env, ora, o_obs, ("split rollout", N, tuple(kw)))
+            _compare_whole_batch(env, ora, o_obs, ("planned rollout", N, tuple(kw)))      # episode_stats also fails on a chunk hand-over fault
             env.close()
         del ora
+    N = cap2 + 8192
+    seats = ("cycle_rush_turn25", "swarm")
+    pid = [evg.EvergladesVecEnv.POLICIES[s_] for s_ in seats]
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    o_obs = ora.reset()
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(150):
+        ora.scripted_actions(pid[0], 0, o_obs, oa)
+        ora.scripted_actions(pid[1], 1, o_obs, oa)
+        o_obs, _, _, _ = ora.step(oa)
+    for kw in (dict(), dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=2))):      # lanes = 2: the chunked form forced over the whole batch
+        env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **kw)
+        assert "chunked" in env.launch_plan(150)[1]
+        env.reset()
+        env.rollout_policies(150, seats[0], seats[1], fused=True, turns_per_launch=150)
+        assert np.array_equal(_np(env._actions), oa)
+        _compare_whole_batch(env, ora, o_obs, ("chunked scripted rollout", tuple(kw)))
+        env.close()

@@ -30,7 +30,11 @@ def step_kernel(name, form):
     multi = FORMS[form][0].split(",")[0]
     if form == "caller" and any(k in name for k in ACTION_KERNELS):
         return True
-    return "evg_step_kernel<%s, 64, %s" % (dtype, FORMS[form][0]) in name or "evg_step4_kernel<%s, %s" % (dtype, multi) in name
+    import re
+    # evg_step_kernel<OT, 64, MULTI, MT[, CHUNKED]>: the keyed-draw instantiations (MT = false) of the form's MULTI, plain or chunked
+    if re.search(r"evg_step_kernel<%s, 64, %s, false(, (true|false))?>" % (dtype, multi), name):
+        return True
+    return "evg_step4_kernel<%s, %s" % (dtype, multi) in name
 
 
 def counter_rows(directory, form):
