@@ -84,7 +84,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def committed_counters(kind, n_local, workload, obs_dtype):
+def committed_counters(kind, n_local, workload, obs_dtype, variant=None):
     """Newest committed counter summary (profiles/*_<kind>.json: tools/pmc_summary.py / tools/sq_summary.py) of THIS build
     (same kernel-source hash), batch size, workload and observation dtype; None when there is none.  Counters cannot be read
     from inside the benchmarked process, so the bench prices its own launches with the per-env-step figures of those passes."""
@@ -94,7 +94,7 @@ def committed_counters(kind, n_local, workload, obs_dtype):
         except Exception:
             continue
         if d.get("kernel_source_hash") == kernel_source_hash() and int(d.get("envs", -1)) == n_local and \
-                d.get("workload", "random") == workload and d.get("obs_dtype", "float32") == obs_dtype:
+                d.get("workload", "random") == workload and d.get("obs_dtype", "float32") == obs_dtype and d.get("variant") == variant:
             d["_file"] = os.path.relpath(f, ROOT)
             return d
     return None
@@ -408,21 +408,29 @@ def main():
         if pmc and roof["bytes_per_env_step"] < 0.5 * mand:
             roof["note"] = ("the counters see fewer bytes than the kernel writes: the working set of this batch (%.0f MB) stays in L2 / Infinity Cache, the launch is "
                             "latency- and issue-bound and `frac` says nothing about it" % (n_local * (1773 + 4 * 210 + 112) / 1e6))
-        # does "hbm" mean DRAM?  The counters are L2 <-> fabric requests and include Infinity-Cache (256 MiB) hits, and the 65 536-env working set
-        # (~180 MB) fits the cache: the same passes at 262 144 envs (~720 MB, far beyond it) settle it
+        # does "hbm" mean DRAM?  FETCH_SIZE / WRITE_SIZE count L2 <-> fabric requests, Infinity-Cache (256 MiB) hits included, and the working set
+        # of 65 536 envs (~180 MB) fits that cache.  Two passes at 262 144 envs settle it: (a) the product's launch -- whole rounds of resident
+        # workgroups one after the other, each round's working set again ~180 MB -- and (b) the chunked form forced over the whole batch
+        # (diagnostic library), which cycles through all 720 MB every few chunks, i.e. really lives beyond the cache.
         big = committed_counters("pmc_traffic", 262144, args.workload, args.obs_dtype)
-        if big and pmc and n_local == 65536:
-            bm = {"envs": 262144, "working_set_MB": round(262144 * (1773 + 4 * 210 + 112) / 1e6), "source": big["_file"], "forms": {}}
-            for k in ("persistent", "one_launch_per_turn"):
-                if k in big["forms"] and k in pmc["forms"]:
-                    fb, fs = big["forms"][k], pmc["forms"][k]
-                    bm["forms"][k] = {"bytes_per_env_step": fb["bytes_per_env_step_steady"], "bytes_per_env_step_at_65536": fs["bytes_per_env_step_steady"],
-                                      "ns_per_env_step": fb["kernel_us_per_turn"] * 1e3 / 262144, "ns_per_env_step_at_65536": fs["kernel_us_per_turn"] * 1e3 / 65536,
-                                      "traffic_TBps": fb["traffic_TBps"], "frac_of_8TBps": fb["frac_of_8TBps"]}
-            pf = bm["forms"].get("persistent")
-            if pf:
-                bm["same_rate_beyond_the_infinity_cache"] = bool(abs(pf["bytes_per_env_step"] / pf["bytes_per_env_step_at_65536"] - 1) < 0.05 and
-                                                                 pf["ns_per_env_step"] / pf["ns_per_env_step_at_65536"] < 1.08)
+        cyc = committed_counters("pmc_traffic", 262144, args.workload, args.obs_dtype, variant="cycled")
+        if pmc and n_local == 65536 and (big or cyc):
+            bm = {"envs": 262144, "working_set_MB": round(262144 * (1773 + 4 * 210 + 112 + 32) / 1e6), "infinity_cache_MB": 268}
+            def cmp_form(d, k):
+                fb, fs = d["forms"][k], pmc["forms"][k]
+                return {"bytes_per_env_step": fb["bytes_per_env_step_steady"], "bytes_per_env_step_at_65536": fs["bytes_per_env_step_steady"],
+                        "ns_per_env_step": fb["kernel_us_per_turn"] * 1e3 / 262144, "ns_per_env_step_at_65536": fs["kernel_us_per_turn"] * 1e3 / 65536,
+                        "traffic_TBps": fb["traffic_TBps"], "frac_of_8TBps": fb["frac_of_8TBps"], "source": d["_file"]}
+            if big:
+                bm["whole_rounds_one_after_the_other"] = {k: cmp_form(big, k) for k in ("persistent", "one_launch_per_turn") if k in big["forms"] and k in pmc["forms"]}
+            if cyc and "persistent" in cyc["forms"]:
+                c = cmp_form(cyc, "persistent")
+                bm["whole_batch_cycled_every_few_chunks"] = c
+                bm["hbm_frac_beyond_the_infinity_cache"] = c["frac_of_8TBps"]
+                bm["conclusion"] = ("the bytes are the same, the rate is not: cycled through a working set the Infinity Cache cannot hold the persistent kernel sustains "
+                                    "%.2f TB/s = %.2f of the HBM peak; the %.2f at 65 536 envs (and in whole rounds at any batch size) is the rate of the L2 <-> Infinity-Cache/HBM "
+                                    "fabric with the round's working set cache-resident" % (c["traffic_TBps"], c["frac_of_8TBps"], pmc["forms"]["persistent"]["frac_of_8TBps"]))
+                roof["bound_is"] = "fabric: L2 <-> Infinity Cache / HBM (working set of a round of resident workgroups ~180 MB < 256 MiB); HBM proper: beyond_mall.hbm_frac_beyond_the_infinity_cache"
             roof["beyond_mall"] = bm
         for leg, key in ((per_turn_launch, "one_launch_per_turn"), (caller_leg, "caller_actions_per_turn")):
             if leg is not None:

@@ -590,7 +590,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
             const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
             if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
             {   // a chunked launch: remember how many units each XCD's queue holds (evg_episode_stats checks that all were taken)
-                const LaunchPlan pl = plan_step(h->S, io, h->caps);
+                const LaunchPlan pl = plan_step(h->S, io, h->cfg.obs_dtype, h->caps);
                 h->last_chunked_units = 0;
                 const LaunchPiece& cp = pl.piece[pl.n - 1];          // a plan has at most one chunked piece: its last
                 if (cp.chunk_turns > 0) {
@@ -852,7 +852,7 @@ int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int bu
     if (!h || !buf || buflen < 1 || turns_per_launch < 1) return fail(EVG_ERR_INVALID, "launch_plan: bad argument");
     StepIO io = make_io(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0, nullptr);
     io.turns = turns_per_launch;
-    const LaunchPlan p = plan_step(h->S, io, h->caps);
+    const LaunchPlan p = plan_step(h->S, io, h->cfg.obs_dtype, h->caps);
     std::string s;
     char tmp[320];
     for (int i = 0; i < p.n; ++i) {

@@ -159,7 +159,7 @@ struct LaunchPlan { int32_t n; LaunchPiece piece[2]; };
 // launchers (evg_kernels.hip)
 int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps);
 int launch_xcd_probe(uint32_t* out /* device [1024] */, void* stream);
-LaunchPlan plan_step(const DevState& S, const StepIO& io, const DeviceCaps& caps);
+LaunchPlan plan_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps);
 int launch_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps, uint32_t* progress_counter, void* stream);
 int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream);
 int launch_random_actions(const DevState& S, int32_t* actions, void* stream);

@@ -1605,7 +1605,7 @@ int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps) {
 // last whole round ran alone at low occupancy for a whole launch (98 304 envs: 30.9 us per turn where 1.5 x 17.0 = 25.5 would be
 // proportional; 65 536 + 4 480 envs cost 28.0 instead of 18.0).  Now:
 //   * the whole rounds but the last: one plain launch, as before;
-//   * the last whole round TOGETHER WITH a remainder of up to kChunkMaxRemainderPct % of a round: one CHUNKED launch -- as many
+//   * the last whole round TOGETHER WITH the remainder, while the two fit the Infinity Cache (kChunkFootprintMax): one CHUNKED launch -- as many
 //     workgroups as the device holds, each taking units (set of 32 envs) x (chunk of kChunkTurns turns) from its XCD's queue and handing
 //     the set on through HBM (see the kernel's prologue): all slots stay busy until the queues run dry (98 304 envs: 26 us per turn,
 //     70 016: 18.0);
@@ -1616,8 +1616,11 @@ int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps) {
 #define EVG_CHUNK_TURNS 25                 // turns per chunk of a chunked launch (a build-time knob so that it can be re-measured with two builds: tools/scaling_lib.py)
 #endif
 [[maybe_unused]] constexpr int kChunkTurns = EVG_CHUNK_TURNS;
-[[maybe_unused]] constexpr int kChunkMaxRemainderPct = 60;
-LaunchPlan plan_step(const DevState& S, const StepIO& io, const DeviceCaps& caps) {
+// A chunked launch cycles through ALL its envs every few chunks, so its working set -- state, observations, orders, results: 2.76 KB per
+// env with float32 observations -- must fit the Infinity Cache (256 MiB on MI355X; HIP has no query for it): measured, us per turn,
+// chunked / the alternative: 98 304 envs (271 MB) 25.8 / 27.5; 104 448 envs (288 MB) 32.5 / ~29.5.
+[[maybe_unused]] constexpr long long kChunkFootprintMax = (256ll << 20) + (256ll << 20) / 50;
+LaunchPlan plan_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps) {
     LaunchPlan p;
     p.n = 1;
     p.piece[0] = LaunchPiece{0, 0, S.N, 0};
@@ -1641,7 +1644,8 @@ LaunchPlan plan_step(const DevState& S, const StepIO& io, const DeviceCaps& caps
     if (N <= cap2) return p;
     const long long full = N / cap2, rem = N - full * cap2;
     if (rem == 0) return p;                         // whole rounds only: one plain launch
-    if (rem * 100 <= cap2 * kChunkMaxRemainderPct && io.turns > kChunkTurns) {
+    const long long bytes_per_env = 1773 + 210 * (obs_dtype == EVG_OBS_F64 ? 8 : (obs_dtype == EVG_OBS_I16 ? 2 : 4)) + 112 + 32;
+    if ((cap2 + rem) * bytes_per_env <= kChunkFootprintMax && io.turns > kChunkTurns) {
         p.n = 0;
         if (full >= 2) p.piece[p.n++] = LaunchPiece{0, 0, (int32_t)((full - 1) * cap2), 0};
         p.piece[p.n++] = LaunchPiece{0, (int32_t)((full - 1) * cap2), (int32_t)N, kChunkTurns};
@@ -1679,7 +1683,7 @@ int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const Dev
     if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
 #endif
     if (!multi) return launch_step_variant<64, false>(S, io, obs_dtype, s);
-    const LaunchPlan plan = plan_step(S, io, caps);
+    const LaunchPlan plan = plan_step(S, io, obs_dtype, caps);
     for (int i = 0; i < plan.n; ++i) {
         const LaunchPiece& pc = plan.piece[i];
         io.env_lo = pc.env_lo; io.env_hi = pc.env_hi;

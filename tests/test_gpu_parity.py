@@ -1381,7 +1381,7 @@ def test_launch_plan_follows_the_device_and_chunked_rollouts_match_oracle(evg, o
                     (cap2, ["two lanes per env, persistent>"]), (2 * cap2, ["two lanes per env, persistent>[envs 0..%d:" % (2 * cap2)]),
                     (cap2 + 1, ["chunked>[envs 0..%d: %d sets of 32 envs x 6 chunks of 25 turns" % (cap2 + 1, s2 + 1)]),
                     (cap2 + cap4a, ["chunked>[envs 0..%d: %d sets of 32 envs x 6 chunks" % (cap2 + cap4a, s2 + s4a // 2)]),
-                    (2 * cap2 + 4480, ["persistent>[envs 0..%d:" % cap2, "chunked>[envs %d..%d:" % (cap2, 2 * cap2 + 4480)]),
+                    (2 * cap2 + 4480 + 7, ["persistent>[envs 0..%d:" % cap2, "chunked>[envs %d..%d:" % (cap2, 2 * cap2 + 4480 + 7)]),
                     (cap2 + cap4b, ["persistent>[envs 0..%d:" % cap2, "four lanes per env, built for 3 waves per SIMD>[envs %d..%d:" % (cap2, cap2 + cap4b)])):
         e = evg.EvergladesVecEnv(N, seed=1)
         n, text = e.launch_plan(150)
@@ -1390,15 +1390,15 @@ def test_launch_plan_follows_the_device_and_chunked_rollouts_match_oracle(evg, o
         assert "chunked" not in e.launch_plan(25)[1] and "chunked" not in e.launch_plan(1)[1]      # nothing to hand on in a launch of one chunk
         e.close()
     seed, steps = 1234, 195                                  # 150-turn launch (6 chunks) + 45-turn launch (2 chunks: 25 + 20)
-    for N in (cap2 + cap4a, cap2 + 4480 + 7, 2 * cap2 + 4480, cap2 + cap4b):
+    for N in (cap2 + cap4a, 2 * cap2 + 4480 + 7, cap2 + cap4b):      # chunked | plain round + chunked (ragged last set) | plain round + four-lane remainder
         ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
         ora.reset()
         for t in range(steps):
             a = ora.random_actions()
             o_obs, _, _, _ = ora.step(a)
         for kw in (dict(), dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=64))):
-            if kw and N > cap2 + cap4a:
-                continue                                     # the forced plain launch is compared at the first two sizes
+            if kw and N != cap2 + cap4a:
+                continue                                     # the forced plain launch is compared at the first size
             env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **kw)
             assert ("chunked" in env.launch_plan(150)[1]) == (not kw and N != cap2 + cap4b)
             env.reset()

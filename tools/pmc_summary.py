@@ -5,7 +5,7 @@
   <name>_pmc_traffic.json   HBM-side bytes per launch / per env-step of the step kernel from the FETCH_SIZE and WRITE_SIZE
                             passes, corrected with the calibration copy of the same passes (tools/pmc_calib.py), keyed by the
                             hash of the kernel sources so that bench.py only uses figures of the build it runs
-usage: python tools/pmc_summary.py <tag> <name> [envs] [workload] [obs_dtype]      e.g.  r02b r02_b"""
+usage: python tools/pmc_summary.py <tag> <name> [envs] [workload] [obs_dtype] [variant]      e.g.  r02b r02_b"""
 import glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _prof import ROOT, FORMS, FORM_KEY, kernel_source_hash, counter_rows, timed_window, trace_durations
@@ -14,6 +14,7 @@ tag, name = sys.argv[1], sys.argv[2]
 ENVS = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "random"
 OBS = sys.argv[5] if len(sys.argv) > 5 else "float32"
+VARIANT = sys.argv[6] if len(sys.argv) > 6 else None      # e.g. "cycled": the chunked form forced over the whole batch (bench.py --diag-lanes 2)
 import _prof
 _prof.OBS_DTYPE = OBS
 _prof.KERNELS_PER_TURN = 2 if WORKLOAD == "random" else 3
@@ -29,7 +30,7 @@ def calib(sub):
 
 calib_f, calib_w = calib("calib_fetch"), calib("calib_write")
 fetch_scale, write_scale = 262144.0 / calib_f, 262144.0 / calib_w            # expected KB / reported
-out = {"kernel_source_hash": kernel_source_hash(), "envs": ENVS, "workload": WORKLOAD, "obs_dtype": OBS,
+out = {"kernel_source_hash": kernel_source_hash(), "envs": ENVS, "workload": WORKLOAD, "obs_dtype": OBS, "variant": VARIANT,
        "commands": {f: open(os.path.join(P, "cmd_%s.txt" % f)).read().strip().replace(ROOT + "/", "").replace(os.environ.get("GRAFT_REPO_ROOT", "\0") + "/", "") for f in FORMS},
        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; bytes = FETCH_SIZE KB x fetch_scale + WRITE_SIZE KB x write_scale "
                  "(the gfx950 correction of MI355X_MICROARCH.md, re-derived by the calibration copy in the same passes); dispatches of the timed window only "
