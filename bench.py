@@ -314,6 +314,18 @@ def main():
         gathered = gather(env.packed_episode_results())
     final_state = env.get_state() if (world == 1 and not args.no_cpu_baseline and args.workload == "random" and played <= 2000) else None
 
+    # ---- N > 1: what the collective carried.  Every rank counts the winners of its own rows on its device; the sum over ranks (one
+    # all-reduce of 4 integers, outside the timed region) must equal what rank 0 counts in the gathered rows.
+    dist_check = None
+    if dist_on:
+        mine_rows = env.packed_episode_results()
+        w = mine_rows[:, 2]
+        local_counts = torch.stack([(w == 0).sum(), (w == 1).sum(), (w == 2).sum(), (w < 0).sum()]).to(torch.int64)
+        summed = local_counts.clone() if args.backend == "nccl" else local_counts.cpu()
+        dist.all_reduce(summed)
+        dist_check = {"wins_p0_p1_tie_unfinished_sum_over_ranks": [int(x) for x in summed.tolist()]}
+
+
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
     # reference's own observation dtype (float64)
     per_turn_launch = caller_leg = obs_f64 = None
@@ -347,17 +359,6 @@ def main():
             d64 = time.perf_counter() - t1
             obs_f64 = {"env_steps_per_s": total * 150 / d64, "ms_per_step": d64 / 150 * 1e3, "kernel_ms": k64 / 150, "turns_per_launch": args.turns_per_launch}
             env64.close()
-
-    # ---- N > 1: what the collective carried.  Every rank counts the winners of its own rows on its device; the sum over ranks (one
-    # all-reduce of 4 integers, outside the timed region) must equal what rank 0 counts in the gathered rows.
-    dist_check = None
-    if dist_on:
-        mine_rows = env.packed_episode_results()
-        w = mine_rows[:, 2]
-        local_counts = torch.stack([(w == 0).sum(), (w == 1).sum(), (w == 2).sum(), (w < 0).sum()]).to(torch.int64)
-        summed = local_counts.clone() if args.backend == "nccl" else local_counts.cpu()
-        dist.all_reduce(summed)
-        dist_check = {"wins_p0_p1_tie_unfinished_sum_over_ranks": [int(x) for x in summed.tolist()]}
 
     if rank == 0:
         value = total * args.steps / dt

@@ -12,11 +12,16 @@ run driver_shape --steps 20 --warmup 5
 run config5 --workload scripted --no-cpu-baseline
 run 4096envs --envs 4096 --no-cpu-baseline
 run int16 --obs-dtype int16 --no-cpu-baseline
+# the N > 1 code path, rehearsed on the one GPU of the box: two ranks over gloo (two processes sharing the card), and RCCL with a one-rank group
+run rehearse_gloo2 --gpus 2 --backend gloo --steps 20 --warmup 5 --no-cpu-baseline
+run rehearse_rccl1 --rehearse-distributed --steps 20 --warmup 5 --no-cpu-baseline
 python - <<P
 import json, glob
 for f in sorted(glob.glob("gpurun_out/bench_${TAG}_*.json")):
     d = json.loads(open(f).read())
     o = d["config"].get("one_launch_per_turn") or {}
-    print("%-28s %.3f G env-steps/s  %.2f us/step  roofline.frac %s  hash %s  per-turn %.3f G" % (f.split("bench_")[1], d["value"] / 1e9, d["ms_per_step"] * 1e3,
-          d["roofline"].get("frac"), d["config"].get("kernel_source_hash"), o.get("env_steps_per_s", 0) / 1e9))
+    c = d["config"].get("caller_actions_per_turn") or {}
+    print("%-28s %.3f G env-steps/s  %.2f us/step  roofline.frac %s  hash %s  per-turn %.3f G (frac %s)  caller actions %.3f G (frac %s)  %s" % (f.split("bench_")[1], d["value"] / 1e9, d["ms_per_step"] * 1e3,
+          d["roofline"].get("frac"), d["config"].get("kernel_source_hash"), o.get("env_steps_per_s", 0) / 1e9, (o.get("roofline") or {}).get("frac"),
+          c.get("env_steps_per_s", 0) / 1e9, (c.get("roofline") or {}).get("frac"), (d.get("distributed") or {}).get("backend", "")))
 P
