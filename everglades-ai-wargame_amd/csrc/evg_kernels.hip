@@ -158,6 +158,22 @@ __device__ __forceinline__ void gen_random_rows(uint32_t seed_lo, uint32_t seed_
     for (int i = 0; i < NA; ++i) rows[i] = make_int2((int)((gp >> (4 * i)) & 15ull), (int)((np_ >> (4 * i)) & 15ull));
 }
 
+// zero a [12][LPW] table of per-lane columns.  With all 64 lanes owning a column (LPW == 64) the table is 3 072 contiguous bytes: three
+// 16-byte-per-lane stores by the whole wave instead of twelve 4-byte ones per lane (an LDS store costs a SIMD ~16 cycles whatever its width)
+template <int LPW>
+__device__ __forceinline__ void zero_columns12(uint32_t (*a)[LPW], int lane, bool envlane) {
+    if constexpr (LPW == WG) {
+        uint4* p = reinterpret_cast<uint4*>(&a[0][0]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) p[lane + WG * j] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        if (envlane) {
+#pragma unroll
+            for (int n = 0; n < 12; ++n) a[n][lane] = 0;
+        }
+    }
+}
+
 // value held by the other player's lane of the same env (lane ^ 1): one DPP quad_perm [1,0,3,2] move, no LDS round trip
 __device__ __forceinline__ int xchg1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 
@@ -640,10 +656,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     const uint32_t contested = (play && !ABLATED(2u)) ? (occ & (uint32_t)xchg1((int)occ)) : 0u;
     if (__any(contested != 0)) {                          // wave-uniform: skip when none of the 32 envs fights
-        if (envlane) {
-#pragma unroll
-            for (int n = 0; n < 12; ++n) L.u.c.FS[n][lane] = 0;
-        }
+        zero_columns12<LPW>(L.u.c.FS, lane, envlane);
         uint32_t key[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
@@ -964,10 +977,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     PHASE(7);
 
     // ---------------- per-node aggregates of this side (post-movement): capture points | units listed << 16
-    if (envlane) {
-#pragma unroll
-        for (int n = 0; n < 12; ++n) L.u.A[n][lane] = 0;
-    }
+    zero_columns12<LPW>(L.u.A, lane, envlane);
     int my_unit_score = 0, my_alive = 0;
     int cntv[12];                      // alive units per group: also what the observation shows (:493)
 #pragma unroll
