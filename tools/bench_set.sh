@@ -18,7 +18,7 @@ run rehearse_rccl1 --rehearse-distributed --steps 20 --warmup 5 --no-cpu-baselin
 python - <<P
 import json, glob
 for f in sorted(glob.glob("gpurun_out/bench_${TAG}_*.json")):
-    d = json.loads(open(f).read())
+    d = json.loads([l for l in open(f) if l.startswith("{")][-1])        # (gloo prints connection notes on stdout before the line)
     o = d["config"].get("one_launch_per_turn") or {}
     c = d["config"].get("caller_actions_per_turn") or {}
     print("%-28s %.3f G env-steps/s  %.2f us/step  roofline.frac %s  hash %s  per-turn %.3f G (frac %s)  caller actions %.3f G (frac %s)  %s" % (f.split("bench_")[1], d["value"] / 1e9, d["ms_per_step"] * 1e3,
