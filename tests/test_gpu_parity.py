@@ -1405,6 +1405,21 @@ def test_launch_plan_follows_the_device_and_chunked_rollouts_match_oracle(evg, o
             env.rollout_random(steps, turns_per_launch=150)
             assert np.array_equal(_np(env._actions), a), (N, kw)
             _compare_whole_batch(env, ora, o_obs, ("planned rollout", N, tuple(kw)))      # episode_stats also fails on a chunk hand-over fault
+            if not kw and N == cap2 + cap4a:
+                # the state a chunked launch leaves in HBM is what every other entry point continues from: two evg_step calls with
+                # caller-supplied orders, then a masked reset, against the oracle
+                ora2 = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+                ora2.reset()
+                ora2.set_state(*[ora.get_state()[k] for k in ("groups", "nodes", "health", "env")])
+                for t in range(2):
+                    a2 = _np(env.random_actions()).copy()
+                    obs2, _, _, info2 = env.step(a2)
+                    o2, _, _, oi2 = ora2.step(a2)
+                    assert np.array_equal(_np(obs2).astype(np.float64), o2) and np.array_equal(_np(info2["scores"]), oi2["scores"]), ("evg_step after a chunked launch", t)
+                mask = (np.arange(N) % 7 == 0).astype(np.uint8)
+                assert np.array_equal(_np(env.reset(mask=mask)).astype(np.float64)[mask != 0], ora2.reset(mask=mask)[mask != 0])
+                check_state(env, ora2.get_state(), "after chunked launch + steps + masked reset")
+                del ora2
             env.close()
         del ora
     N = cap2 + 8192
