@@ -1,7 +1,8 @@
 #!/bin/bash
 # A/B on ONE box: bench several builds of the library alternately through bench.py's diagnostic --library switch.
 # usage (inside gpurun): LIBS="libevg_base.so libevg.so" bash tools/ab.sh [extra bench.py args]   -> gpurun_out/ab.txt
-# (libevg_base.so = a copy of an earlier libevg.so kept beside the working build)
+# (libevg_base.so = a copy of an earlier libevg.so kept beside the working build; it must be an ABI-3 build -- export evg_launch_plan --,
+#  e.g. `git stash; make -C everglades-ai-wargame_amd/csrc; cp .../libevg.so .../libevg_base.so; git stash pop; make ...`)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 LIBS=${LIBS:-"libevg_base.so libevg.so"}
