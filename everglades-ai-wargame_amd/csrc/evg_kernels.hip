@@ -1357,17 +1357,29 @@ __global__ void __launch_bounds__(256) evg_mt_seed_kernel(DevState S, const uint
 // 7 distinct nodes of 1..11 per player, partial Fisher-Yates on nibble-packed permutations
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int32_t* actions) {
+    // One thread per (env, player) draws its 7 rows; the block's 256 x 56 bytes are contiguous in the output, so they go through LDS and
+    // leave as 16-byte-per-lane coalesced stores (a thread's own rows are 56 bytes apart from its neighbour's: direct stores would touch
+    // 28 cache lines per instruction).
+    __shared__ int2 rows_lds[256 * NA];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 2 * S.N) return;
-    const int e = idx >> 1, p = idx & 1;
-    const int turn = (int)(S.env[e] & 0xFFu);
-    const uint32_t episode = S.episode[e];
-    const uint32_t env_id = S.env_id_base + (uint32_t)e;
-    int2 rows[NA];
-    gen_random_rows(S.seed_lo, S.seed_hi, env_id, episode, turn, p, rows);
-    int2* out = reinterpret_cast<int2*>(actions) + (size_t)idx * NA;
+    const int total = 2 * S.N;
+    if (idx < total) {
+        const int e = idx >> 1, p = idx & 1;
+        const int turn = (int)(S.env[e] & 0xFFu);
+        const uint32_t episode = S.episode[e];
+        const uint32_t env_id = S.env_id_base + (uint32_t)e;
+        int2 rows[NA];
+        gen_random_rows(S.seed_lo, S.seed_hi, env_id, episode, turn, p, rows);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) out[i] = rows[i];
+        for (int i = 0; i < NA; ++i) rows_lds[threadIdx.x * NA + i] = rows[i];
+    }
+    __syncthreads();
+    const int first = blockIdx.x * 256;                                 // first (env, player) of this block
+    const int nrows = min(256, total - first) * NA;                      // int2 rows this block holds (a multiple of 7)
+    const uint4* src = reinterpret_cast<const uint4*>(rows_lds);
+    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<int2*>(actions) + (size_t)first * NA);     // 256 x 56 B per block: 16-byte aligned
+    for (int v = threadIdx.x; 2 * v + 1 < nrows; v += 256) dst[v] = src[v];
+    if ((nrows & 1) && threadIdx.x == 0) reinterpret_cast<int2*>(dst)[nrows - 1] = rows_lds[nrows - 1];  // odd tail of the last block
 }
 
 // standalone form of the scripted opponents: one thread per env, view = the observation tensor
