@@ -426,10 +426,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-#ifdef EVG_DIAG      // experiment knobs (tools/stagger.py): delay = slot x a + simd x b sleeps of 256 cycles, a = ablate[15:8] - 1, b = ablate[23:16]
-    const int kStaggerSlot = (A->io_.ablate >> 8) & 0xFFu ? (int)((A->io_.ablate >> 8) & 0xFFu) - 1 : 20, kStaggerSimd = (int)((A->io_.ablate >> 16) & 0xFFu);
+#ifdef EVG_DIAG      // experiment knobs (tools/stagger.py): delay = slot x a + simd x b sleeps of 64 cycles, a = ablate[15:8] - 1, b = ablate[23:16]
+    const int kStaggerSlot = (A->io_.ablate >> 8) & 0xFFu ? (int)((A->io_.ablate >> 8) & 0xFFu) - 1 : 84, kStaggerSimd = (int)((A->io_.ablate >> 16) & 0xFFu);
 #else
-    constexpr int kStaggerSlot = 20, kStaggerSimd = 0;      // x 256 cycles (s_sleep 4)
+    constexpr int kStaggerSlot = 84, kStaggerSimd = 0;      // x 64 cycles (s_sleep 1)
 #endif
     // ---- prologue loads: the constant tables (one blob, already in its LDS layout) and this lane's state (env fastest; the two player rows of a group index interleave
     // across lanes).  Every load is issued before the first LDS store, so the launch pays ONE memory round trip here
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // (only while the whole grid is resident at once -- STEP_F_STAGGER, set by launch_step from the device's capacity: up to
             // 2 048 workgroups = 65 536 envs on a whole MI355X; a larger grid queues behind itself and its waves start at different times anyway)
             const int nsleep = (io.flags & STEP_F_STAGGER) ? (int)(hw & 1u) * kStaggerSlot + (int)((hw >> 4) & 3u) * kStaggerSimd : 0;
-            for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(4);
+            for (int i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(1);
             // (issue priority for either wave of the pair makes a single-turn launch no shorter: for the late wave 32.5 -> 38.0 us,
             // for the early wave no change; A/B on one box)
         }
