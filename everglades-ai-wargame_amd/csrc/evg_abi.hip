@@ -817,7 +817,8 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
 
 #ifdef EVG_DIAG
 /* Diagnostic libraries only (libevg_diag.so / libevg_stamps.so; declared in no public header).
- *   ablate          bit0 orders, bit1 combat, bit2 movement, bit4 observation write-out, bit5 state store are skipped
+ *   ablate          bit0 orders, bit1 combat, bit2 movement, bit4 observation write-out, bit5 state store are skipped; bit6: a chunked launch never
+ *                   publishes the first chunk of its first set (the fault path: its successor gives up after ~1 s and flags the handle)
  *   lanes_per_wave  0 (default: what the product library launches), 2 (experiment: persistent rollouts of a batch beyond what the device holds run the
  *                   CHUNKED form over the whole batch, i.e. with a working set larger than the Infinity Cache), 64 (the two-lanes-per-env kernel at every batch size and in both
  *                   launch forms), 32 (16 envs per wavefront + 32 helper lanes) or 4 (the four-lanes-per-env kernel in both launch forms)

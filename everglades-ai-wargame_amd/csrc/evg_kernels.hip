@@ -1279,6 +1279,9 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // publish the chunk to the XCD's other workgroups: every store of this wave (state words, health rows, outputs) has reached the L2
     // they share (s_waitcnt vmcnt(0); the vector L1 is write-through), then the flag.  No L2 write-back: the set never leaves this XCD.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef EVG_DIAG      // fault-path test (ablate bit 6): the first chunk of the launch's first set is never published, its successor must give up and flag the handle
+    if (!(ABLATED(64u) && wg_chunk == 0 && wg_set == 0))
+#endif
     if (threadIdx.x == 0) __hip_atomic_store(S.progress + (e0 >> 5), io.progress_base + (uint32_t)wg_chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     WAVE_SYNC();                                         // the next unit's LDS traffic stays behind this one's
     }   // units

@@ -1443,3 +1443,29 @@ def test_launch_plan_follows_the_device_and_chunked_rollouts_match_oracle(evg, o
         assert np.array_equal(_np(env._actions), oa)
         _compare_whole_batch(env, ora, o_obs, ("chunked scripted rollout", tuple(kw)))
         env.close()
+
+
+def test_a_lost_chunk_hand_over_ends_the_launch_and_is_reported(evg):
+    """The safety net of the chunked form: if a set's chunk is never published (simulated through the diagnostic library), the workgroup
+    that took the set's next chunk does not spin for ever -- its poll is bounded (about a second), it flags the handle and plays on, every
+    workgroup leaves when the queues are empty -- and evg_episode_stats reports the fault instead of returning results."""
+    import time
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    N = 32 * 8 * cus + 2048
+    env = evg.EvergladesVecEnv(N, seed=3, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=64))
+    assert "chunked" in env.launch_plan(150)[1]
+    env.reset()
+    t0 = time.perf_counter()
+    env.rollout_random(150, turns_per_launch=150)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert 0.2 < dt < 20.0, dt                                   # one bounded wait, then the grid drained
+    with pytest.raises(evg.EvgError, match="hand a set of envs on"):
+        env.episode_stats()
+    env.close()
+    ok = evg.EvergladesVecEnv(N, seed=3, auto_reset=True, library=evg._lib.DIAG_LIB_PATH)      # the same library without the knob: no fault
+    ok.reset()
+    ok.rollout_random(150, turns_per_launch=150)
+    assert ok.episode_stats()["totals"][0] >= N
+    ok.close()
