@@ -22,6 +22,10 @@ what a Gym consumer gets from env.step(): `one_launch_per_turn` (orders drawn in
 `caller_actions_per_turn` (per turn evg_random_actions into a caller tensor, then evg_step(actions): the reference's
 loop evaluate.py:143-152 with the policy's output arriving in a tensor) -- each with its own roofline object.
 
+The stdout line is the COMPACT form of the result (every number, ~3 KB: a driver that keeps only the tail of the output must
+still see one whole JSON object); `--details FILE` also writes the full object with its explanatory strings (~8 KB), which is
+what tools/bench_set.sh commits under profiles/.
+
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); environments shard by
 contiguous global id (weak scaling: 65 536 per GPU) and the only collective is the gather of episode
 results (one RCCL gather to rank 0 over xGMI, 16 bytes per env).  Rank 0 prints ONE JSON line.
@@ -180,6 +184,78 @@ def cpu_baseline(seed, budget_s=12.0):
                        "(BASELINE.md, measured in the build container)" % (n, turns))
 
 
+def _r(x, n=4):
+    """numbers of the compact line: n significant digits"""
+    if isinstance(x, float):
+        return float("%.*g" % (n, x))
+    return x
+
+
+def compact_line(full):
+    """The ONE line printed on stdout: every field of the contract and the numbers of every leg, without the explanatory strings (a driver
+    that keeps only the tail of the output must still see a whole JSON object: the full object is ~8 KB, this one ~2.5 KB; --details FILE
+    writes the full one, and the lines committed under profiles/ are full ones)."""
+    def roof(r):
+        if not r:
+            return None
+        keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "bytes_per_env_step", "bytes_source", "launch_form", "launches_timed",
+                "turns_per_launch_timed", "kernel_launches_per_rollout_launch", "bound_is", "note")
+        o = {k: _r(r[k], 5) for k in keep if k in r and r[k] is not None}
+        if "traffic" not in o:
+            o["traffic"] = None
+        if "bound_is" in o:
+            o["bound_is"] = "fabric L2<->InfinityCache/HBM, round's working set cache-resident; HBM proper: beyond_mall"
+        if "note" in o:
+            o["note"] = "working set cache-resident: latency/issue-bound, frac meaningless"
+        if "kernel" in r:
+            o["kernel"] = r["kernel"].split(" | ")[0][:160]
+        bm = r.get("beyond_mall")
+        if bm:
+            c = bm.get("whole_batch_cycled_every_few_chunks") or {}
+            w = (bm.get("whole_rounds_one_after_the_other") or {}).get("persistent") or {}
+            o["beyond_mall"] = {"envs": bm["envs"], "working_set_MB": bm["working_set_MB"], "frac_in_rounds_of_cache_size": _r(w.get("frac_of_8TBps")),
+                                "hbm_frac_beyond_the_infinity_cache": _r(bm.get("hbm_frac_beyond_the_infinity_cache")),
+                                "ns_per_env_step_rounds_cycled_65536": [_r(w.get("ns_per_env_step")), _r(c.get("ns_per_env_step")), _r(c.get("ns_per_env_step_at_65536") or w.get("ns_per_env_step_at_65536"))],
+                                "sources": [x for x in (w.get("source"), c.get("source")) if x]}
+        return o
+
+    def leg(l):
+        if not l:
+            return None
+        o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "launches_per_turn", "turns_per_launch") if k in l}
+        if l.get("roofline"):
+            o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("bound", "achieved", "peak", "frac", "bytes_per_env_step", "bytes_source") if l["roofline"].get(k) is not None}
+        return o
+
+    c = full["config"]
+    out = {k: _r(full[k], 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    obs_name = c["workload"].rsplit("obs ", 1)[-1].split(" ")[0]
+    out["config"] = {"workload": "%d concurrent DemoMap games per GPU, %s, persistent rollout form, auto-reset, obs %s [N,2,105]" % (
+                         c["envs_per_gpu"], "random_actions vs random_actions drawn on device" if "random_actions" in c["workload"] else
+                         "on-device Cycle_BRush_Turn25 vs SwarmAgent fused into the step kernel (BASELINE config 5)", obs_name),
+                     "window": "desynchronised steady state (150-turn pre-roll, episode phases hash(e) mod 150) + 150 settle turns + warmup",
+                     **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash", "episodes_finished_rank0",
+                                          "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
+                     "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")), "obs_float64": leg(c.get("obs_float64"))}
+    out["roofline"] = roof(full["roofline"])
+    if "roofline_valu_issue" in full:
+        v = full["roofline_valu_issue"]
+        out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "valu_insts_per_wave_turn", "source")}
+    if "distributed" in full:
+        d = dict(full["distributed"])
+        d["collective"] = d["collective"].split(" (")[0]
+        d["per_rank"] = [{k: _r(v, 5) for k, v in r.items()} for r in d.get("per_rank") or []]
+        out["distributed"] = d
+    if "cpu_baseline" in full:
+        b = full["cpu_baseline"]
+        out["cpu_baseline"] = {"value": _r(b["value"], 5), "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "obs_dtype": b.get("obs_dtype"),
+                               "sample": b["sample"].split(", C oracle")[0] + "; C oracle (port of the reference's turn loop), OpenMP over envs"}
+        if "same_games_as_gpu" in b:
+            g = b["same_games_as_gpu"]
+            out["cpu_baseline"]["same_games_as_gpu"] = {k: g[k] for k in ("envs", "turns", "equal", "cpu_wins_p0_p1_tie", "gpu_wins_p0_p1_tie")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +274,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--rehearse-distributed", action="store_true", help="diagnostics only: run the N > 1 code path (process group, pack + gather, per-rank times) with a ONE-rank group on one GPU")
     ap.add_argument("--caller-actions", action="store_true", help="profiling runs: the MAIN leg runs the caller-supplied-actions path (per turn evg_random_actions into a tensor + evg_step); needs --turns-per-launch 1")
+    ap.add_argument("--details", default="", help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
     ap.add_argument("--diag-lanes", type=int, default=0, help="diagnostics only: kernel variant of libevg_diag.so (evg_diag_configure lanes)")
     args = ap.parse_args()
@@ -486,7 +563,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.seed)
             if final_state is not None:
                 out["cpu_baseline"]["same_games_as_gpu"] = cpu_parity(args.seed, n_local, played - PHASES, st, final_state)
-        print(json.dumps(out), flush=True)
+        if args.details:
+            with open(args.details, "w") as f:
+                f.write(json.dumps(out) + "\n")
+        print(json.dumps(compact_line(out), separators=(",", ":")), flush=True)
     env.close()
     if dist_on:
         dist.barrier()

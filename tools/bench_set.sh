@@ -6,7 +6,8 @@ set -o pipefail
 TAG=${1:-r02}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-run() { name=$1; shift; timeout -k 10 400 python bench.py "$@" > gpurun_out/bench_${TAG}_$name.json 2> gpurun_out/bench_${TAG}_$name.err || { tail -5 gpurun_out/bench_${TAG}_$name.err; exit 1; }; }
+# stdout = the compact line the driver sees; --details = the full object (what is committed under profiles/)
+run() { name=$1; shift; timeout -k 10 400 python bench.py --details gpurun_out/bench_${TAG}_$name.full.json "$@" > gpurun_out/bench_${TAG}_$name.json 2> gpurun_out/bench_${TAG}_$name.err || { tail -5 gpurun_out/bench_${TAG}_$name.err; exit 1; }; }
 run final
 run driver_shape --steps 20 --warmup 5
 run config5 --workload scripted --no-cpu-baseline
@@ -17,7 +18,7 @@ run rehearse_gloo2 --gpus 2 --backend gloo --steps 20 --warmup 5 --no-cpu-baseli
 run rehearse_rccl1 --rehearse-distributed --steps 20 --warmup 5 --no-cpu-baseline
 python - <<P
 import json, glob
-for f in sorted(glob.glob("gpurun_out/bench_${TAG}_*.json")):
+for f in sorted(x for x in glob.glob("gpurun_out/bench_${TAG}_*.json") if not x.endswith(".full.json")):
     d = json.loads([l for l in open(f) if l.startswith("{")][-1])        # (gloo prints connection notes on stdout before the line)
     o = d["config"].get("one_launch_per_turn") or {}
     c = d["config"].get("caller_actions_per_turn") or {}
