@@ -703,8 +703,9 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         PHASE(3);
 
         // Stage 1: wave-wide work list (one item per fighting group) and damage-pool layout, by prefix scan.  The items of the
-        // 12-unit group (gid 11) are listed AFTER all others: only that group needs a second block of draws (more than 8 units)
-        // and the health slots 8..11, so every round of 64 items but the last runs the short 8-unit code.
+        // 12-unit group (gid 11) are listed BEFORE all others: only that group needs a second block of draws (more than 8 units)
+        // and the health slots 8..11, so only the FIRST round of 64 items -- whose lanes are all busy anyway -- runs the long code,
+        // and the last round, 18 items on average, holds 8-unit groups only: phase B deals those to two lanes each.
         const int nf_a = __popc(fmask & 0x7FFu), nf_b = (int)((fmask >> 11) & 1u);
         const int packed = nf_a | (nf_b << 10) | (ndw << 17);   // three counts in one scan: <= 704 items (10 bits), <= 64 (7 bits), <= 2112 words (12 bits)
         int incl = packed;
@@ -730,15 +731,16 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int ref_a = second ? mid_a : 0, ref_b = second ? mid_b : 0, ref_d = second ? mid_d : 0;
             const int end_a = first ? mid_a : tot_a, end_b = first ? mid_b : tot_b, end_d = first ? mid_d : tot_d;
             const int na = end_a - ref_a, nitems = na + (end_b - ref_b), ndwords = end_d - ref_d;
+            const int nb = nitems - na;                          // items of the 12-unit group: listed FIRST (see phase B)
             if (inpass) {
-                int wi = excl_a - ref_a;
+                int wi = nb + excl_a - ref_a;
                 uint32_t f = fmask & 0x7FFu;
                 while (f) {
                     const uint32_t gid = (uint32_t)__ffs(f) - 1u;
                     f &= f - 1;
                     L.u.c.W[wi++] = (uint16_t)((uint32_t)lane | (gid << 6));
                 }
-                if (nf_b) L.u.c.W[na + excl_b - ref_b] = (uint16_t)((uint32_t)lane | (11u << 6));
+                if (nf_b) L.u.c.W[excl_b - ref_b] = (uint16_t)((uint32_t)lane | (11u << 6));
                 int doff = excl_d - ref_d;
                 uint32_t c = contested;
                 while (c) {
@@ -850,7 +852,16 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // Phase B (:573-644): one lane per fighting group; the uid-th alive unit of the snapshot (list-order
             // prefix + rank among the group's alive slots) takes its summed damage.  Both directions read only
             // the snapshot and the pool, so they are simultaneous like in the reference.
-            for (int it = lane; it < nitems; it += WG) {
+            // An instruction costs a wavefront the same whether 64 or 16 of its lanes are active (profiles/r03_m_exec_mask_issue_rates.txt),
+            // and a wavefront has 82 items per turn on average: one full round and one with 18 items.  That sparse last round -- 8-unit
+            // groups only, thanks to the list order -- is dealt to TWO lanes per item when it has at most 32 items: each lane takes four
+            // of the eight unit slots, the pair exchanges the dead-unit mask and the half sums by DPP (the sum keeps numpy's pairwise
+            // order: (h0+h1)+(h2+h3) is the left half, (h4+h5)+(h6+h7) the right one).
+            constexpr bool kSplitLastRound = LPW == WG;
+            const int rem_items = nitems & (WG - 1), full_items = nitems - rem_items;
+            const bool split_last = kSplitLastRound && rem_items > 0 && rem_items <= WG / 2 && full_items >= nb;
+            const int nmain = split_last ? full_items : nitems;
+            for (int it = lane; it < nmain; it += WG) {
                 const uint32_t item = L.u.c.W[it];
                 const int SL = (int)(item & 63u), gid = (int)(item >> 6), side = SL & 1;
                 const uint32_t sp = L.u.c.SNAP[gid][SL];
@@ -944,6 +955,77 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const uint32_t avg = alive ? (uint32_t)(int)(sum / (double)alive) : 0u;          // :491 truncation
                     const uint32_t w = L.G[gid][SL];
                     L.G[gid][SL] = (w & ~(G_MASK_M | G_AVG_M)) | (newmask << G_MASK_S) | (avg << G_AVG_S);
+                }
+            }
+            if (split_last) {
+                const int it = full_items + (lane >> 1), hf = lane & 1;      // item and which half of its unit slots (0: slots 0..3, 1: slots 4..7)
+                if (it < nitems) {
+                    const uint32_t item = L.u.c.W[it];
+                    const int SL = (int)(item & 63u), gid = (int)(item >> 6), side = SL & 1;      // gid < 11: an 8-unit group
+                    const uint32_t sp = L.u.c.SNAP[gid][SL];
+                    const int node = (int)((sp >> 12) & 15u);
+                    const uint32_t mask = sp & 0xFFu;
+                    const uint32_t doff = L.u.c.FS[node][SL] & 0xFFFFu;
+                    const uint32_t base = (sp >> 16) & 0xFFu;
+                    const uint32_t run0 = doff * 4u + base, w0i = run0 >> 2, sh0 = run0 & 3u;
+                    uint32_t dw[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) dw[q] = L.u.c.DP[min(w0i + (uint32_t)q, (uint32_t)(DP_CAP - 1))];
+                    const uint32_t cnt = (uint32_t)__popc(mask);                                      // 1..8
+                    uint32_t a0 = __builtin_amdgcn_alignbyte(dw[1], dw[0], sh0), a1 = __builtin_amdgcn_alignbyte(dw[2], dw[1], sh0);
+                    {
+                        const uint64_t keep = cnt >= 8u ? ~0ull : ((1ull << (8u * cnt)) - 1ull);
+                        a0 &= (uint32_t)keep; a1 &= (uint32_t)(keep >> 32);
+                    }
+                    if ((a0 | a1) != 0u) {                                                        // the same for both lanes of the pair
+                        double* row = S.health + (size_t)(e0 + (SL >> 1)) * (2 * NU) + side * NU + gid * 8 + hf * 4;
+                        double h[4];
+                        {
+                            const double2* r2 = reinterpret_cast<const double2*>(row);
+                            const double2 v0 = r2[0], v1 = r2[1];
+                            h[0] = v0.x; h[1] = v0.y; h[2] = v1.x; h[3] = v1.y;
+                        }
+                        const uint64_t tn_s = L.tab.nib[7 + side];
+                        const uint32_t type = (uint32_t)((tn_s >> (4 * gid)) & 15u);
+                        const int ctrl_by = (int)((L.NW[node][SL >> 1] >> 10) & 3u) - 1;
+                        const int di = (int)type * 12 + (ctrl_by == side ? node : 0);                // :592-597 (fort bonus dead)
+                        const double denom = L.tab.den[di], rcp = L.tab.rcp[di];
+                        uint32_t deadmask = 0;
+                        auto apply_hits4 = [&](auto fast) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t sl = (uint32_t)(4 * hf + j);                          // this lane's slot
+                                const uint32_t sel = (uint32_t)__popc(mask & ((1u << sl) - 1u)) | 0x0C0C0C00u;
+                                const uint32_t d = __builtin_amdgcn_perm(a1, a0, sel);
+                                double loss;
+                                if constexpr (decltype(fast)::value) {
+                                    const double a = (double)__umul24(10u, d);
+                                    const double q0 = a * rcp;
+                                    loss = __builtin_fma(__builtin_fma(-denom, q0, a), rcp, q0);
+                                } else {
+                                    loss = (10.0 * (double)d) / denom;                                // :601
+                                }
+                                const double hv = h[j] - loss;                                        // :609
+                                const bool dead = hv <= 0.0;                                          // :615-618
+                                h[j] = dead ? 0.0 : hv;
+                                deadmask |= dead ? (1u << sl) : 0u;
+                            }
+                        };
+                        if (fast_div) apply_hits4(std::true_type{}); else apply_hits4(std::false_type{});
+                        double2* w2 = reinterpret_cast<double2*>(row);
+                        w2[0] = make_double2(h[0], h[1]);
+                        w2[1] = make_double2(h[2], h[3]);
+                        const uint32_t newmask = mask & ~(deadmask | (uint32_t)xchg1((int)deadmask));
+                        const double mine = (h[0] + h[1]) + (h[2] + h[3]);
+                        const double other = __hiloint2double(xchg1(__double2hiint(mine)), xchg1(__double2loint(mine)));
+                        const double sum = hf ? other + mine : mine + other;                          // left half + right half (np.sum's pairwise order)
+                        const int alive = __popc(newmask);
+                        const uint32_t avg = alive ? (uint32_t)(int)(sum / (double)alive) : 0u;      // :491 truncation
+                        if (hf == 0) {
+                            const uint32_t w = L.G[gid][SL];
+                            L.G[gid][SL] = (w & ~(G_MASK_M | G_AVG_M)) | (newmask << G_MASK_S) | (avg << G_AVG_S);
+                        }
+                    }
                 }
             }
             WAVE_SYNC();
