@@ -58,8 +58,8 @@ for form, (tail, tpl, nwin) in FORMS.items():
                                     "traffic_TBps": per_launch / mean_ns / 1e3, "frac_of_8TBps": per_launch / mean_ns / 1e3 / 8.0,
                                     "kernels_per_turn": kpt,
                                     "vgpr_allocated": 2 * fm[-1]["vgpr"], "vgpr_rocprofv3_column": fm[-1]["vgpr"],
-                                    "vgpr_note": "rocprofv3's VGPR_Count column counts in units of two registers on gfx950: 92 = 184 allocated = the compiler's 181 "
-                                                 "(make resource-usage) rounded up to the allocation granule of 8; single-turn 100 = 200 allocated (198 used)",
+                                    "vgpr_note": "rocprofv3's VGPR_Count column counts in units of two registers on gfx950: the value printed is half of the allocation, which is the "
+                                                 "compiler's count (make resource-usage) rounded up to the allocation granule of 8",
                                     "agpr": fm[-1]["agpr"], "sgpr": fm[-1]["sgpr"], "lds_bytes": fm[-1]["lds"], "scratch": fm[-1]["scratch"]}
     src = glob.glob(os.path.join(P, form + "_stats", "*", "*_kernel_stats.csv"))[0]
     lines = open(src).read().splitlines()
