@@ -259,3 +259,35 @@ def test_bench_window_helpers():
                     assert 971 <= f["bytes_per_env_step_steady"] < 4530 and f["state_round_trip_bytes_per_env"] in (0, 320)
             else:
                 assert 1000 < d["kernels"]["persistent"]["valu_insts_per_wave_turn"] < 10000
+
+
+def test_bench_stdout_line_is_compact_and_complete():
+    """bench.py prints the COMPACT form of its result: a driver that keeps only the tail of the output must still see one whole JSON
+    object.  Every full line committed under profiles/ for this round compacts to less than 3.6 KB (the size of a line a driver is known
+    to have captured whole) and keeps every field of the contract: the metric block, config.workload, roofline {bound, achieved, peak,
+    unit, frac, traffic}, cpu_baseline {value, unit, cores, kind, sample} and the numbers of both per-turn legs."""
+    import glob
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("evg_bench2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r03_p_bench_*.json")) if "compact" not in f)
+    assert len(files) >= 5
+    for f in files:
+        full = json.loads(open(f).read())
+        line = json.dumps(bench.compact_line(full), separators=(",", ":"))
+        assert len(line) < 3600, (f, len(line))
+        c = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in c, (f, k)
+        assert abs(c["value"] / full["value"] - 1) < 1e-5 and c["metric"] == full["metric"] and "workload" in c["config"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in c["roofline"], (f, k)
+        assert abs(c["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-3
+        if "cpu_baseline" in full:
+            for k in ("value", "unit", "cores", "kind", "sample"):
+                assert k in c["cpu_baseline"]
+        for leg in ("one_launch_per_turn", "caller_actions_per_turn"):
+            if full["config"].get(leg):
+                assert c["config"][leg]["roofline"]["frac"] > 0 and c["config"][leg]["kernel_ms"] <= c["config"][leg]["ms_per_step"]
