@@ -236,7 +236,8 @@ def compact_line(full):
                      "window": "desynchronised steady state (150-turn pre-roll, episode phases hash(e) mod 150) + 150 settle turns + warmup",
                      **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash", "episodes_finished_rank0",
                                           "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
-                     "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")), "obs_float64": leg(c.get("obs_float64"))}
+                     "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")), "obs_float64": leg(c.get("obs_float64")),
+                     "without_observations": leg(c.get("without_observations"))}
     out["roofline"] = roof(full["roofline"])
     if "roofline_valu_issue" in full:
         v = full["roofline_valu_issue"]
@@ -330,14 +331,15 @@ def main():
                                    diag=dict(lanes=args.diag_lanes) if args.diag_lanes else None)
         env.reset()
 
-        def rollout(nsteps, timed, tpl, fused=True):
+        def rollout(nsteps, timed, tpl, fused=True, observe=True):
             """nsteps turns through the native rollout driver (evg_rollout_random / evg_rollout_policies, enqueued from C on torch's
             current stream).  fused: the step kernel draws / evaluates the orders of both seats itself; not fused (tpl must be 1):
             per turn the action kernel(s) write the orders into a tensor and evg_step reads them -- the caller-supplied-actions path.
             Returns the summed stream time in ms (HIP events recorded on that stream: around every persistent launch, or around the
             whole loop of single-turn launches)."""
-            out = (env.rollout_random(nsteps, time_kernel=timed, fused=fused, turns_per_launch=tpl) if args.workload == "random" else
-                   env.rollout_policies(nsteps, "cycle_rush_turn25", "swarm", time_kernel=timed, fused=fused, turns_per_launch=tpl))
+            kw = dict(time_kernel=timed, fused=fused, turns_per_launch=tpl, observe=observe, record_actions=observe)
+            out = (env.rollout_random(nsteps, **kw) if args.workload == "random" else
+                   env.rollout_policies(nsteps, "cycle_rush_turn25", "swarm", **kw))
             return out[-1] * nsteps if timed else 0.0
 
         desynchronise(env, first, args.workload, rollout)
@@ -405,7 +407,7 @@ def main():
 
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
     # reference's own observation dtype (float64)
-    per_turn_launch = caller_leg = obs_f64 = None
+    per_turn_launch = caller_leg = obs_f64 = no_obs_leg = None
     if world == 1 and not args.no_extra_legs:
         def per_turn_leg(fused):
             """150 turns, one step launch per turn, warmed; wall clock between two barriers and the stream time between two
@@ -426,6 +428,17 @@ def main():
             caller_leg = per_turn_leg(False)
             caller_leg["path"] = ("per turn: evg_random_actions -> caller tensor [N,2,7,2] -> evg_step(actions) (evaluate.py:143-152 with on-device agents)" if args.workload == "random" else
                                   "per turn: evg_scripted_actions x 2 (reading the previous observations) -> caller tensor -> evg_step(actions)")
+        if args.turns_per_launch > 1 and main_fused:
+            # the persistent form without observations and without recording the orders (evg_rollout_*(obs_out = NULL, actions_buf = NULL)):
+            # what the evaluation harness runs (everglades_amd.evaluate: it reads only the episode results, evaluate.py:143-181)
+            rollout(16, True, args.turns_per_launch, True, False)
+            barrier()
+            t1 = time.perf_counter()
+            kq = rollout(150, True, args.turns_per_launch, True, False)
+            barrier()
+            dq = time.perf_counter() - t1
+            no_obs_leg = {"env_steps_per_s": total * 150 / dq, "ms_per_step": dq / 150 * 1e3, "kernel_ms": kq / 150, "turns_per_launch": args.turns_per_launch,
+                          "what": "persistent rollout, no observation image / write-out, orders not recorded: rewards, done flags, scores and episode results only"}
         if args.obs_dtype != "float64":
             env64, rollout64 = make_env("float64")
             rollout64(8, True, args.turns_per_launch, main_fused)
@@ -535,7 +548,7 @@ def main():
                                  "then 150 settle turns, --warmup turns and the K timed turns",
                        "envs_per_gpu": n_local, "total_envs": total, "turns_per_launch": tpl, "turns_of_last_timed_launch": turns_last_launch,
                        "launch_form": main_form,
-                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "obs_float64": obs_f64, "parallelism": "env-sharded x%d" % world,
+                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "obs_float64": obs_f64, "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
                        "kernel_source_hash": kernel_source_hash(),
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],

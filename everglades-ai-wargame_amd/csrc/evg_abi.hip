@@ -565,7 +565,8 @@ int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int p
 static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
                         uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
-    if (steps < 1 || !actions_buf || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, actions_buf, reward_out, done_out required");
+    if (steps < 1 || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, reward_out, done_out required");
+    if (!actions_buf && !fused) return fail(EVG_ERR_INVALID, "rollout: actions_buf is required unless the step kernel produces the orders itself (fused >= 1)");
     EVG_ON_DEVICE(h);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipStream_t s_ = s;

@@ -1227,6 +1227,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // everglades_env.py:158-171), written as int16 straight into the wave's output image in LDS.
     // Board part by node ID (every LDS read has a constant offset): slot s of player 1's view shows node p1_node_map[s] (:437-439),
     // so node n is written to slot p1inv[n]; player 0's view is the identity.
+    // (a rollout without an observation buffer -- evg_rollout_*(obs_out = NULL): the evaluation harness, which reads only the episode
+    // results -- skips the image and the write-out altogether: a sixth of the turn's instructions and 55 % of its bytes)
+    const bool want_obs = io.obs != nullptr;
+    if (want_obs) {
     uint32_t nw_n[12], ou_n[12], res_n[12];
 #pragma unroll
     for (int n = 1; n <= NN; ++n) {
@@ -1260,6 +1264,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             o[4] = (int16_t)cntv[k];
         }
     }
+    }   // want_obs
     PHASE(10);
 
     // ---------------- store state (coalesced)
@@ -1290,7 +1295,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---------------- observation write-out: the wave's 32 x 210 values are contiguous in the output; every lane
     // converts 16 bytes' worth per iteration (conflict-free LDS reads, fully coalesced 1 KiB stores per wave)
-    if (io.obs && !ABLATED(16u)) {
+    if (want_obs && !ABLATED(16u)) {
         constexpr int EP = 16 / (int)sizeof(OT);          // elements per 16-byte vector
         constexpr int NVEC = LPW * OBS / EP;
         const int limit = nvalid * OBS2;

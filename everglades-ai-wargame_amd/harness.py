@@ -59,7 +59,8 @@ def evaluate(player0, player1, episodes, num_envs=4096, seed=0, device=None, alp
     for _ in range(rounds):
         obs = env.reset()
         if both_native:
-            env.rollout_policies(max_turns, player0, player1, fused=True, turns_per_launch=turns_per_launch)   # finished envs stay frozen
+            # finished envs stay frozen; the loop reads only the episode results, so no observations are written and no orders recorded
+            env.rollout_policies(max_turns, player0, player1, fused=True, turns_per_launch=turns_per_launch, observe=False, record_actions=False)
         else:
             for _t in range(max_turns):
                 acts = env._actions

@@ -246,30 +246,39 @@ class EvergladesVecEnv(object):
     def scripted_reset(self):
         self._check(self.L.evg_scripted_reset(self._h, self._stream()))
 
-    def rollout_random(self, steps, time_kernel=False, fused=True, turns_per_launch=1):
+    def rollout_random(self, steps, time_kernel=False, fused=True, turns_per_launch=1, observe=True, record_actions=True):
         """`steps` turns of random-vs-random play driven from native code (evg_rollout_random): per turn the
         on-device random_actions generator fills self._actions, then the step kernel runs (fused=True: the step kernel draws the same orders itself and stores them in
         self._actions -- one launch per turn; turns_per_launch > 1: persistent form, each launch plays that many
-        consecutive turns per wavefront, outputs still written every turn).  Returns the outputs of
+        consecutive turns per wavefront, outputs still written every turn).  observe=False / record_actions=False (fused forms only):
+        no observations are written (self.obs keeps its old content) / the orders are not stored -- for loops that read only rewards,
+        done flags and episode results.  Returns the outputs of
         the last turn like step(); with time_kernel=True also the average step-kernel time in ms (synchronises)."""
         ms = C.c_float(0.0)
         p = self._p                     # cached raw pointers of the env's own buffers: the call itself is the only host work before the launch
-        rc = self.L.evg_rollout_random(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p["_actions"], p["obs"], p["reward"],
+        if not fused and not (observe and record_actions):
+            raise ValueError("observe=False / record_actions=False need the fused forms (the unfused form passes the orders through self._actions)")
+        rc = self.L.evg_rollout_random(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p["_actions"] if record_actions else None,
+                                       p["obs"] if observe else None, p["reward"],
                                        p["done"], p["winner"], p["scores"], p["status"], C.byref(ms) if time_kernel else None, self._stream())
         if rc:
             self._check(rc)
         out = (self.obs, self.reward, self.done, self._info)
         return out + (float(ms.value),) if time_kernel else out
 
-    def rollout_policies(self, steps, policy0, policy1, time_kernel=False, fused=True, turns_per_launch=1):
+    def rollout_policies(self, steps, policy0, policy1, time_kernel=False, fused=True, turns_per_launch=1, observe=True, record_actions=True):
         """`steps` turns of on-device policy0 (seat 0) vs policy1 (seat 1), driven from native code (evg_rollout_policies).
         fused=False: two agent launches per turn read self.obs (which must hold the current observations; it does after
         reset()/step()); fused=True: the step kernel evaluates both agents from the on-chip state, one launch per turn or --
-        turns_per_launch > 1 -- the persistent form.  Identical results."""
+        turns_per_launch > 1 -- the persistent form.  Identical results.  observe=False / record_actions=False (fused forms only): no
+        observations are written / the orders are not stored (the evaluation harness: it reads only the episode results)."""
         ms = C.c_float(0.0)
         p0 = self.POLICIES[policy0] if isinstance(policy0, str) else int(policy0)
         p1 = self.POLICIES[policy1] if isinstance(policy1, str) else int(policy1)
-        self._check(self.L.evg_rollout_policies(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p0, p1, self._ptr(self._actions), self._ptr(self.obs), self._ptr(self.reward),
+        if not fused and not (observe and record_actions):
+            raise ValueError("observe=False / record_actions=False need the fused forms (the agents of the unfused form read self.obs)")
+        self._check(self.L.evg_rollout_policies(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p0, p1, self._ptr(self._actions) if record_actions else None,
+                                               self._ptr(self.obs) if observe else None, self._ptr(self.reward),
                                                self._ptr(self.done), self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status),
                                                C.byref(ms) if time_kernel else None, self._stream()))
         out = (self.obs, self.reward, self.done, self._info)

@@ -225,6 +225,9 @@ int evg_scripted_reset(evg_handle* h, void* stream);
  * fused >= 2: additionally each launch plays up to `fused` consecutive turns per wavefront (persistent form: the
  * state of a wavefront's envs stays in LDS/registers between turns; observations, rewards, actions ... are still
  * written every turn, so the buffers hold the last turn as before).  Results are identical in all three forms.
+ * With fused >= 1 obs_out and actions_buf may be NULL: the rollout then writes no observations (the step kernel skips the
+ * observation image and its write-out: a sixth of a turn's instructions and 55 % of its bytes) and / or does not record the orders --
+ * what an evaluation loop needs, which reads only rewards, done flags and the episode results (evaluate.py:143-181).
  * Outputs as in evg_step (they hold the LAST step when the call returns).  If step_kernel_ms (host
  * pointer) is not NULL the work is bracketed by hipEvents on `stream`, the call synchronises the stream and stores the
  * stream time per turn in milliseconds: persistent form -- the duration of each launch (or launch plan, see

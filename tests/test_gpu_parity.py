@@ -1469,3 +1469,44 @@ def test_a_lost_chunk_hand_over_ends_the_launch_and_is_reported(evg):
     ok.rollout_random(150, turns_per_launch=150)
     assert ok.episode_stats()["totals"][0] >= N
     ok.close()
+
+
+def test_rollouts_without_observations_play_the_same_games(evg, oracle_mod):
+    """evg_rollout_*(obs_out = NULL, actions_buf = NULL): the step kernel skips the observation image and its write-out and does not record
+    the orders; state, rewards, episode results and win counters are those of the observing rollout (and of the oracle), the observation
+    and order tensors keep their old content.  Both kernel mappings (four-lane at 3 000 envs, two-lane at 65 536 + chunked beyond), random
+    and scripted orders; the evaluation harness uses this form."""
+    import torch
+    cap2 = 32 * 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    for N, steps in ((3000, 170), (cap2, 170), (cap2 + 2048, 160)):
+        for scripted in (False, True):
+            a = evg.EvergladesVecEnv(N, seed=11, auto_reset=True)
+            b = evg.EvergladesVecEnv(N, seed=11, auto_reset=True)
+            a.reset(); b.reset()
+            obs_before, act_before = b.obs.clone(), b._actions.clone()
+            if scripted:
+                a.rollout_policies(steps, "cycle_rush_turn25", "swarm", turns_per_launch=150)
+                b.rollout_policies(steps, "cycle_rush_turn25", "swarm", turns_per_launch=150, observe=False, record_actions=False)
+            else:
+                a.rollout_random(steps, turns_per_launch=150)
+                b.rollout_random(steps, turns_per_launch=150, observe=False, record_actions=False)
+            sa, sb = a.get_state(), b.get_state()
+            for k in ("groups", "nodes", "health", "env"):
+                assert np.array_equal(sa[k], sb[k]), (N, scripted, k)
+            ea, eb = a.episode_stats(), b.episode_stats()
+            for k in ("returns", "length", "winner", "totals"):
+                assert np.array_equal(ea[k], eb[k]), (N, scripted, k)
+            assert torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done) and torch.equal(a.scores, b.scores)
+            assert torch.equal(b.obs, obs_before) and torch.equal(b._actions, act_before)          # untouched
+            assert torch.equal(a.observe(), b.observe())                                              # and recoverable from the state
+            if N == 3000 and not scripted:
+                ora = oracle_mod.Oracle(N, seed=11, auto_reset=True)
+                ora.reset()
+                for t in range(steps):
+                    ora.step_noobs(ora.random_actions())
+                check_state(b, ora.get_state(), "no-observation rollout vs oracle")
+            a.close(); b.close()
+    with pytest.raises(ValueError):
+        e = evg.EvergladesVecEnv(64, seed=1)
+        e.reset()
+        e.rollout_random(3, fused=False, observe=False)
