@@ -272,7 +272,7 @@ def test_bench_stdout_line_is_compact_and_complete():
     spec = importlib.util.spec_from_file_location("evg_bench2", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r03_p_bench_*.json")) if "compact" not in f)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r03_q_bench_*.json")) if "compact" not in f)
     assert len(files) >= 5
     for f in files:
         full = json.loads(open(f).read())
