@@ -280,6 +280,9 @@ def main():
     ap.add_argument("--diag-lanes", type=int, default=0, help="diagnostics only: kernel variant of libevg_diag.so (evg_diag_configure lanes)")
     args = ap.parse_args()
 
+    # multi-process GPU work on this image needs dmabuf IPC (the host driver supports nothing else): RCCL fails with
+    # "hipIpcGetMemHandle: invalid argument" without it.  The boxes export it already; make sure the ranks see it either way.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started directly instead of through torch.distributed.run: launch the ranks as child processes (nothing has
         # touched the GPU yet) and leave with their exit code
