@@ -17,10 +17,13 @@ the K timed turns are ceil(K / 150) launches of the persistent step kernel, and 
 wavefront plus a start-up and a host synchronisation, which weigh more on a 20-turn launch (--steps 20: 19-20 us per
 step) than on 150-turn ones (the default --steps 450: 16-17 us per step).  Both shapes are kept under profiles/.
 
-Besides the headline (persistent rollout form) the line carries, under config, two legs that pay one launch per turn --
-what a Gym consumer gets from env.step(): `one_launch_per_turn` (orders drawn inside the step kernel) and
+Besides the headline (persistent rollout form) the line carries, under config, three legs that pay one step launch per turn --
+what a Gym consumer gets from env.step(): `one_launch_per_turn` (orders drawn inside the step kernel),
 `caller_actions_per_turn` (per turn evg_random_actions into a caller tensor, then evg_step(actions): the reference's
-loop evaluate.py:143-152 with the policy's output arriving in a tensor) -- each with its own roofline object.
+loop evaluate.py:143-152 with both policies' output arriving in a tensor) and `learner_vs_bot_per_turn` (the loop the
+reference's scripts actually run, evaluate.py:85-93,143-152: a caller on seat 0 whose 7 rows arrive in a tensor -- stand-in:
+evg_random_actions_seat --, an on-device bot on seat 1 evaluated INSIDE the step kernel, only the caller's observation
+written: evg_step_vs_policy) -- each with its own roofline object.
 
 The stdout line is the COMPACT form of the result (every number, ~3 KB: a driver that keeps only the tail of the output must
 still see one whole JSON object); `--details FILE` also writes the full object with its explanatory strings (~8 KB), which is
@@ -50,6 +53,8 @@ SURVEY_ALGO_BYTES_PER_ENV_STEP = 4530
 # reward 8 + done 1 + winner 1 + scores 8 + status 1 = 19  ->  971 B, plus the float64 health rows of the groups
 # that were hit (64 B read + 64 B written per group row, 96 for group 11) -- see DESIGN.md section 3.
 MANDATORY_OUTPUT_BYTES = {"float32": 971, "float64": 971 + 840, "int16": 971 - 420}
+# the learner-seat turn (evg_step_vs_policy): one seat's observation 420 (f32), the caller's orders 56 written by its policy and 56 read, the same 19
+MANDATORY_OUTPUT_BYTES_LEARNER = {"float32": 420 + 112 + 19, "float64": 840 + 112 + 19, "int16": 210 + 112 + 19}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0   # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction: what a SIMD sustains with 2 or 4
                                                      # waves on this kernel's instruction mix (tools/micro/inst_rate.hip, profiles/r02_q_*: 4.3-4.8 cycles per
@@ -236,7 +241,8 @@ def compact_line(full):
                      "window": "desynchronised steady state (150-turn pre-roll, episode phases hash(e) mod 150) + 150 settle turns + warmup",
                      **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash", "episodes_finished_rank0",
                                           "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
-                     "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")), "obs_float64": leg(c.get("obs_float64")),
+                     "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")),
+                     "learner_vs_bot_per_turn": leg(c.get("learner_vs_bot_per_turn")), "obs_float64": leg(c.get("obs_float64")),
                      "without_observations": leg(c.get("without_observations"))}
     out["roofline"] = roof(full["roofline"])
     if "roofline_valu_issue" in full:
@@ -275,6 +281,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--rehearse-distributed", action="store_true", help="diagnostics only: run the N > 1 code path (process group, pack + gather, per-rank times) with a ONE-rank group on one GPU")
     ap.add_argument("--caller-actions", action="store_true", help="profiling runs: the MAIN leg runs the caller-supplied-actions path (per turn evg_random_actions into a tensor + evg_step); needs --turns-per-launch 1")
+    ap.add_argument("--learner-seat", action="store_true", help="profiling runs: the MAIN leg runs the learner-seat path (per turn evg_random_actions_seat into a tensor + evg_step_vs_policy); needs --turns-per-launch 1")
+    ap.add_argument("--opponent", default="random", help="the on-device bot of the learner-seat leg (a name from everglades_amd._lib.POLICY_NAMES); random = the headline's game mix")
     ap.add_argument("--details", default="", help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
     ap.add_argument("--diag-lanes", type=int, default=0, help="diagnostics only: kernel variant of libevg_diag.so (evg_diag_configure lanes)")
@@ -335,6 +343,9 @@ def main():
         env.reset()
 
         def rollout(nsteps, timed, tpl, fused=True, observe=True):
+            if fused == "learner":                           # per turn: evg_random_actions_seat -> tensor [N,7,2] -> evg_step_vs_policy (bot inside the step kernel)
+                out = env.rollout_vs(nsteps, args.opponent, seat=0, time_kernel=timed)
+                return out[-1] * nsteps if timed else 0.0
             """nsteps turns through the native rollout driver (evg_rollout_random / evg_rollout_policies, enqueued from C on torch's
             current stream).  fused: the step kernel draws / evaluates the orders of both seats itself; not fused (tpl must be 1):
             per turn the action kernel(s) write the orders into a tensor and evg_step reads them -- the caller-supplied-actions path.
@@ -349,9 +360,9 @@ def main():
         rollout(PHASES, True, args.turns_per_launch, main_fused)   # settle: one more episode length in the launch form that is timed (also creates its timing events)
         return env, rollout
 
-    main_fused = not args.caller_actions                      # --caller-actions (profiling runs): the main leg itself pays two launches per turn
-    if args.caller_actions and args.turns_per_launch != 1:
-        raise SystemExit("--caller-actions needs --turns-per-launch 1 (orders from a tensor exist in the single-turn form only)")
+    main_fused = "learner" if args.learner_seat else (not args.caller_actions)   # --caller-actions / --learner-seat (profiling runs): the main leg itself pays two launches per turn
+    if (args.caller_actions or args.learner_seat) and args.turns_per_launch != 1:
+        raise SystemExit("--caller-actions / --learner-seat need --turns-per-launch 1 (orders from a tensor exist in the single-turn form only)")
     env, rollout = make_env(args.obs_dtype)
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
     gather = evg.ResultGather(n_local, total, device, force=dist_on)   # preallocated buffers; rank 0 receives (one RCCL gather)
@@ -410,7 +421,7 @@ def main():
 
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
     # reference's own observation dtype (float64)
-    per_turn_launch = caller_leg = obs_f64 = no_obs_leg = None
+    per_turn_launch = caller_leg = learner_leg = obs_f64 = no_obs_leg = None
     if world == 1 and not args.no_extra_legs:
         def per_turn_leg(fused):
             """150 turns, one step launch per turn, warmed; wall clock between two barriers and the stream time between two
@@ -423,15 +434,19 @@ def main():
             d1 = time.perf_counter() - t1
             return {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": k1 / 150,
                     "kernel_ms_is": "stream time per turn: two HIP events around the whole 150-turn leg / 150 (launches back to back, gaps included"
-                                    + ("" if fused else "; the action kernel of the turn included") + ")",
-                    "launches_per_turn": 1 if fused else (2 if args.workload == "random" else 3)}
-        if args.turns_per_launch > 1 or not main_fused:
+                                    + ("" if fused is True else "; the action kernel of the turn included") + ")",
+                    "launches_per_turn": 2 if fused == "learner" else (1 if fused else (2 if args.workload == "random" else 3))}
+        if args.turns_per_launch > 1 or main_fused is not True:
             per_turn_launch = per_turn_leg(True)
-        if main_fused:
+        if main_fused != "learner":
+            learner_leg = per_turn_leg("learner")
+            learner_leg["path"] = ("per turn: evg_random_actions_seat -> caller tensor [N,7,2] (seat 0) -> evg_step_vs_policy(opponent = on-device `%s` on seat 1, evaluated inside the step "
+                                   "kernel; only seat 0's observation [N,105] written) -- evaluate.py:85-93,143-152 with a learner on one seat" % args.opponent)
+        if main_fused is True:
             caller_leg = per_turn_leg(False)
             caller_leg["path"] = ("per turn: evg_random_actions -> caller tensor [N,2,7,2] -> evg_step(actions) (evaluate.py:143-152 with on-device agents)" if args.workload == "random" else
                                   "per turn: evg_scripted_actions x 2 (reading the previous observations) -> caller tensor -> evg_step(actions)")
-        if args.turns_per_launch > 1 and main_fused:
+        if args.turns_per_launch > 1 and main_fused is True:
             # the persistent form without observations and without recording the orders (evg_rollout_*(obs_out = NULL, actions_buf = NULL)):
             # what the evaluation harness runs (everglades_amd.evaluate: it reads only the episode results, evaluate.py:143-181)
             rollout(16, True, args.turns_per_launch, True, False)
@@ -467,6 +482,7 @@ def main():
         def hbm_roofline(form_key, kernel_ms, turns_per_launch_timed):
             """roofline object of one launch form: bytes per env-step from the committed counter pass of THIS build for that form
             (None: the unavoidable output bytes, a lower bound) x envs / the stream time per turn measured here"""
+            mand = MANDATORY_OUTPUT_BYTES_LEARNER[args.obs_dtype] if form_key == "learner_vs_bot_per_turn" else MANDATORY_OUTPUT_BYTES[args.obs_dtype]
             r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": kernel_ms, "mandatory_output_bytes_per_env_step": mand}
             form = pmc["forms"].get(form_key) if pmc else None
             if form:
@@ -485,7 +501,7 @@ def main():
                                           % (kernel_source_hash(), form_key, n_local, args.workload, args.obs_dtype)})
             return r
 
-        main_form = "persistent" if tpl > 1 else ("caller_actions_per_turn" if args.caller_actions else "one_launch_per_turn")
+        main_form = "persistent" if tpl > 1 else ("caller_actions_per_turn" if args.caller_actions else ("learner_vs_bot_per_turn" if args.learner_seat else "one_launch_per_turn"))
         roof = hbm_roofline(main_form, step_kernel_ms, args.steps / launches)
         n_launch, plan_text = env.launch_plan(tpl)
         roof.update({"kernel": plan_text, "kernel_launches_per_rollout_launch": n_launch, "launch_form": main_form,
@@ -526,7 +542,7 @@ def main():
                                     "fabric with the round's working set cache-resident" % (c["traffic_TBps"], c["frac_of_8TBps"], pmc["forms"]["persistent"]["frac_of_8TBps"]))
                 roof["bound_is"] = "fabric: L2 <-> Infinity Cache / HBM (working set of a round of resident workgroups ~180 MB < 256 MiB); HBM proper: beyond_mall.hbm_frac_beyond_the_infinity_cache"
             roof["beyond_mall"] = bm
-        for leg, key in ((per_turn_launch, "one_launch_per_turn"), (caller_leg, "caller_actions_per_turn")):
+        for leg, key in ((per_turn_launch, "one_launch_per_turn"), (caller_leg, "caller_actions_per_turn"), (learner_leg, "learner_vs_bot_per_turn")):
             if leg is not None:
                 leg["roofline"] = hbm_roofline(key, leg["kernel_ms"], 1)
                 leg["roofline"]["kernel"] = env.launch_plan(1)[1]
@@ -551,7 +567,7 @@ def main():
                                  "then 150 settle turns, --warmup turns and the K timed turns",
                        "envs_per_gpu": n_local, "total_envs": total, "turns_per_launch": tpl, "turns_of_last_timed_launch": turns_last_launch,
                        "launch_form": main_form,
-                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "obs_float64": obs_f64, "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
+                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "learner_vs_bot_per_turn": learner_leg, "obs_float64": obs_f64, "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
                        "kernel_source_hash": kernel_source_hash(),
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],

@@ -6,14 +6,15 @@ whose kernels are hand-written HIP for gfx950.  Import as `everglades_amd` (alia
 repository root; this directory's name is not a legal Python identifier).
 """
 from . import _lib
-from ._lib import EvgError, load as load_library
+from ._lib import EvgError, EvgFault, load as load_library
 from .tables import default_tables, tables_from_json
 from .vec_env import EvergladesVecEnv
+from .pipeline import PipelinedVecEnv
 from .env import EvergladesEnv, canonical_actions
 from .distributed import shard_range, gather_episode_results, win_counts, ResultGather
 from .harness import evaluate, evaluate_all, proportion_confint_normal
 
-__all__ = ["EvergladesVecEnv", "EvergladesEnv", "EvgError", "load_library", "default_tables", "tables_from_json",
+__all__ = ["EvergladesVecEnv", "PipelinedVecEnv", "EvergladesEnv", "EvgError", "EvgFault", "load_library", "default_tables", "tables_from_json",
            "canonical_actions", "shard_range", "gather_episode_results", "win_counts", "ResultGather", "evaluate", "evaluate_all",
            "proportion_confint_normal"]
 

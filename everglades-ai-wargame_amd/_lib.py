@@ -14,14 +14,15 @@ STAMPS_LIB_PATH = os.path.join(HERE, "libevg_stamps.so")  # `make -C csrc stamps
 NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105
 MAX_SCORE = 3700
 OBS_F32, OBS_F64, OBS_I16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
+ERR_FAULT = -5        # EVG_ERR_FAULT: the handle's fault word is set (evg_check_fault)
 RNG_KEYED_PHILOX, RNG_STOCK_MT19937 = 0, 1
 POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "all_cycle", "base_rush_v1", "bull_rush",
                 "cycle_target_node", "cycle_target_node1", "cycle_target_node11", "cycle_target_node11P2", "dfs_attack", "no_action",
                 "random_actions_delay", "same_commands"]      # index = EVG_POLICY_* of include/evg.h (agents/State_Machine/<name>.py)
 POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
-EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_fog_of_war", "evg_sightings", "evg_smart_state", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
+EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat", "evg_random_actions_seat", "evg_smart_state_seat", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war", "evg_sightings", "evg_smart_state", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
            "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_launch_plan", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
@@ -41,12 +42,16 @@ class EvgConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int32), ("device_id", C.c_int32),
         ("seed", C.c_uint64), ("env_id_base", C.c_uint64), ("obs_dtype", C.c_int32), ("auto_reset", C.c_int32),
-        ("rng_mode", C.c_int32), ("reserved0", C.c_int32), ("tables", EvgTables),
+        ("rng_mode", C.c_int32), ("cache_mib", C.c_int32), ("tables", EvgTables),
     ]
 
 
 class EvgError(RuntimeError):
     pass
+
+
+class EvgFault(EvgError):
+    """EVG_ERR_FAULT: a chunked rollout launch of the handle failed to hand a set of envs on; its state and results are not valid."""
 
 
 _libs = {}
@@ -105,6 +110,12 @@ def load(path=None):
     L.evg_reset.argtypes = [vp, vp, vp, vp]
     L.evg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.evg_observe.argtypes = [vp, vp, vp]
+    L.evg_step_vs_policy.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.evg_observe_seat.argtypes = [vp, C.c_int, vp, vp]
+    L.evg_random_actions_seat.argtypes = [vp, C.c_int, vp, vp]
+    L.evg_smart_state_seat.argtypes = [vp, vp, vp, vp]
+    L.evg_check_fault.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.evg_rollout_vs_policy.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]
     L.evg_fog_of_war.argtypes = [vp, vp, vp, vp]
     L.evg_sightings.argtypes = [vp, vp, vp]
     L.evg_smart_state.argtypes = [vp, C.c_int, vp, vp, vp]
@@ -134,4 +145,4 @@ def load(path=None):
 
 def check(rc, lib=None):
     if rc != 0:
-        raise EvgError("libevg error %d: %s" % (rc, (lib or load()).evg_last_error().decode("utf-8", "replace")))
+        raise (EvgFault if rc == ERR_FAULT else EvgError)("libevg error %d: %s" % (rc, (lib or load()).evg_last_error().decode("utf-8", "replace")))

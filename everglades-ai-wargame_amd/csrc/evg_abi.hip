@@ -73,9 +73,7 @@ struct evg_handle {
     DevState S;
     DevTables* d_tables = nullptr;
     DeviceCaps caps;                    // what the device holds at once (query_device_caps at evg_create): drives the launch plan
-    uint32_t progress_counter = 1;      // next unused value of the chunk flags (DevState::progress), monotonic over launches
-    uint64_t last_chunked_units = 0;    // units of the last chunked launch (all XCDs) and per XCD: checked against the queues by evg_episode_stats
-    uint32_t last_chunked_units_x[16] = {0};
+    uint32_t* fault_seen_host = nullptr;   // host address of DevState::fault_seen (mapped host memory): non-zero <=> some bit of the fault word was set
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
 #ifdef EVG_DIAG                         // diagnostic libraries only, set through evg_diag_configure (never from the environment)
@@ -108,6 +106,21 @@ static int dev_alloc(evg_handle* h, Tp** p, size_t count) {
     if (e != hipSuccess) return fail(EVG_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(Tp), hipGetErrorString(e));
     h->allocs.push_back(q);
     *p = reinterpret_cast<Tp*>(q);
+    return EVG_OK;
+}
+
+// The fault word of a handle (DevState::fault; include/evg.h, evg_check_fault).  The caller has synchronised whatever it wants covered: kernels
+// store the host-mapped mirror with system scope, so it is visible here after that synchronisation and a healthy handle costs one host load.
+static int check_fault(evg_handle* h, uint32_t* word_out = nullptr) {
+    uint32_t fault = 0;
+    if (*reinterpret_cast<volatile uint32_t*>(h->fault_seen_host) != 0u) {
+        HIP_TRY(hipMemcpy(&fault, h->S.fault, sizeof(fault), hipMemcpyDeviceToHost));
+        if (!fault) fault = 0x80000000u;        // the mirror says so, the word does not: report it all the same
+    }
+    if (word_out) *word_out = fault;
+    if (fault) return fail(EVG_ERR_FAULT, "a chunked rollout launch failed to hand a set of envs on (fault word %u: 1 = a workgroup gave up waiting for a predecessor chunk, 2 = a workgroup "
+                                          "ran on an XCD the create-time probe did not see, 4 = a queue of a chunked launch was not drained): the state and the results of this handle "
+                                          "are not valid; destroy it", fault);
     return EVG_OK;
 }
 
@@ -368,6 +381,8 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     memset(&h->caps, 0, sizeof(h->caps));
     rc = query_device_caps(cfg->device_id, cfg->obs_dtype, &h->caps);
     if (rc) { delete h; return fail(EVG_ERR_HIP, "querying the device's capacity failed: %s", hipGetErrorString((hipError_t)rc)); }
+    if (cfg->cache_mib < 0 || cfg->cache_mib > (1 << 20)) { delete h; return fail(EVG_ERR_INVALID, "cache_mib"); }
+    if (cfg->cache_mib > 0) h->caps.cache_bytes = (int64_t)cfg->cache_mib << 20;
     const size_t N = (size_t)cfg->num_envs;
     DevState& S = h->S;
     memset(&S, 0, sizeof(S));
@@ -390,9 +405,17 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (!rc) rc = dev_alloc(h, &S.agent_cycle, 2 * N);
     if (!rc) rc = dev_alloc(h, &S.agent_swarm, 2 * N);
     if (!rc) rc = dev_alloc(h, &S.agent_dfs, 2 * N);
-    if (!rc) rc = dev_alloc(h, &S.progress, (N + 31) / 32 + 1);
-    if (!rc) rc = dev_alloc(h, &S.queue, 1024);          // 16 queue counters; the create-time XCD probe borrows the rest
+    if (!rc) rc = dev_alloc(h, &S.queue, 1024 + (N + 31) / 32 + 1);      // 16 queue counters on lines of their own (the create-time XCD probe borrows the 1 024 words) ...
+    if (!rc) S.progress = S.queue + 1024;                                // ... and the per-set progress flags behind them: one memset zeroes both
     if (!rc) rc = dev_alloc(h, &S.fault, 1);
+    if (!rc) {        // host-mapped mirror of "the fault word is not zero" (check_fault)
+        void* hp = nullptr;
+        void* dp = nullptr;
+        hipError_t he = hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped);
+        if (he == hipSuccess) { *reinterpret_cast<uint32_t*>(hp) = 0u; h->fault_seen_host = reinterpret_cast<uint32_t*>(hp); he = hipHostGetDevicePointer(&dp, hp, 0); }
+        if (he != hipSuccess) rc = fail(EVG_ERR_ALLOC, "mapped host word: %s", hipGetErrorString(he));
+        S.fault_seen = reinterpret_cast<uint32_t*>(dp);
+    }
     if (!rc) rc = dev_alloc(h, &h->d_tables, 1);
     uint32_t *mt_key = nullptr, *mt_pos = nullptr;       // attached to S after the create-time reset, which must not draw
     if (!rc && cfg->rng_mode == EVG_RNG_STOCK_MT19937) {
@@ -405,13 +428,26 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     rc = dev_alloc(h, &h->stamps, (size_t)((cfg->num_envs + 15) / 16) * 16);
     if (rc) { evg_destroy(h); return rc; }
 #endif
+    {
+        // The chunked form's hand-over (evg_kernels.hip, "WHAT THIS RELIES ON") assumes ordinary coarse-grained device memory, cached in the L2 of the XCD
+        // that touches it: refuse to run on anything else (managed or host memory behind these pointers) instead of corrupting state silently.
+        const void* must_be_device[] = {S.grp, S.stamp, S.node, S.env, S.episode, S.health, S.ep_ret, S.fin_ret, S.fin_len, S.fin_win, S.progress};
+        for (const void* q : must_be_device) {
+            hipPointerAttribute_t at;
+            const hipError_t ae = hipPointerGetAttributes(&at, q);
+            if (ae != hipSuccess || at.type != hipMemoryTypeDevice || at.isManaged) {
+                evg_destroy(h);
+                return fail(EVG_ERR_HIP, "the state arrays must be plain device memory (hipMalloc); got type %d managed %d (%s)", ae == hipSuccess ? (int)at.type : -1,
+                            ae == hipSuccess ? (int)at.isManaged : -1, hipGetErrorString(ae));
+            }
+        }
+    }
     hipError_t e = hipMemcpy(h->d_tables, &h->host_tables, sizeof(DevTables), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(S.episode, 0, N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(S.fin_ret, 0, 2 * N * sizeof(float));
     if (e == hipSuccess) e = hipMemset(S.fin_len, 0, N * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(S.fin_win, 0xFF, N);
     if (e == hipSuccess) e = hipMemset(S.totals, 0, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(S.progress, 0, ((N + 31) / 32 + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(S.fault, 0, sizeof(uint32_t));
     if (e == hipSuccess) {
         // the XCDs of this device (8 on a whole MI355X; a partitioned device has fewer): 1 024 one-wave workgroups report their XCC id
@@ -419,7 +455,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
         e = (hipError_t)launch_xcd_probe(S.queue, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMemcpy(ids.data(), S.queue, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemset(S.queue, 0, 1024 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(S.queue, 0, (1024 + (N + 31) / 32 + 1) * sizeof(uint32_t));
         uint32_t seen = 0;
         for (uint32_t v : ids) if (v < 16u) seen |= 1u << v;
         S.xcd_rank = ~0ull;
@@ -449,6 +485,7 @@ void evg_destroy(evg_handle* h) {
     if (!h) return;
     DeviceGuard guard(h->cfg.device_id);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->fault_seen_host) (void)hipHostFree(h->fault_seen_host);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
     delete h;
 }
@@ -457,7 +494,7 @@ int evg_num_envs(const evg_handle* h) { return h ? h->S.N : 0; }
 
 int evg_state_bytes_per_env(const evg_handle* h) {
     (void)h;
-    return 24 * 4 + 6 * 4 + 6 * 4 + 4 + 4 + 2 * NU * 8 + 2 * 4;   // grp, stamp, node, env, episode, health, ep_ret
+    return kStateBytesPerEnv;       // grp, stamp, node, env, episode, health, ep_ret (evg_device.h)
 }
 
 int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream) {
@@ -474,7 +511,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, 0, 0, nullptr);
-    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
+    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -483,7 +520,34 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr);
-    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
+    const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
+    if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out, float* reward_out,
+                       uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (!actions || !obs_seat_out || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, obs_seat_out, reward_out and done_out are required");
+    if (seat < 0 || seat > 1 || opponent_policy < 0 || opponent_policy >= EVG_POLICY_COUNT) return fail(EVG_ERR_INVALID, "seat / opponent_policy out of range");
+    if ((reinterpret_cast<uintptr_t>(obs_seat_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "obs_seat_out must be 16-byte aligned");
+    if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_step_vs_policy: keyed-Philox handles only (the stock-entropy mode has no fused bots)");
+    EVG_ON_DEVICE(h);
+    StepIO io = make_io(h, actions, obs_seat_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 2, opponent_policy, opponent_policy, nullptr);
+    io.seat = seat; io.actions_both = actions_both_seats ? 1 : 0;
+    const int rc = launch_step_seat(h->S, io, h->cfg.obs_dtype, h->caps, stream);
+    if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream) {
+    if (!h || !obs_seat_out || seat < 0 || seat > 1) return fail(EVG_ERR_INVALID, "bad argument");
+    if ((reinterpret_cast<uintptr_t>(obs_seat_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "obs_seat_out must be 16-byte aligned");
+    if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_observe_seat: keyed-Philox handles only");
+    EVG_ON_DEVICE(h);
+    StepIO io = make_io(h, nullptr, obs_seat_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr);
+    io.seat = seat;
+    const int rc = launch_step_seat(h->S, io, h->cfg.obs_dtype, h->caps, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -491,7 +555,16 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream) {
 int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
     if (!h || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_ON_DEVICE(h);
-    const int rc = launch_random_actions(h->S, actions_out, stream);
+    const int rc = launch_random_actions(h->S, actions_out, -1, stream);
+    if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_random_actions_seat(evg_handle* h, int seat, int32_t* actions_seat_out, void* stream) {
+    if (!h || !actions_seat_out || seat < 0 || seat > 1) return fail(EVG_ERR_INVALID, "bad argument");
+    if ((reinterpret_cast<uintptr_t>(actions_seat_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "actions_seat_out must be 16-byte aligned");
+    EVG_ON_DEVICE(h);
+    const int rc = launch_random_actions(h->S, actions_seat_out, seat, stream);
     if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -524,7 +597,15 @@ int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream) {
 int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream) {
     if (!h || !obs || !features_out || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
     EVG_ON_DEVICE(h);
-    const int rc = launch_smart_state(h->S, player, obs, features_out, h->cfg.obs_dtype, stream);
+    const int rc = launch_smart_state(h->S, player, obs, 0, features_out, h->cfg.obs_dtype, stream);
+    if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_out, void* stream) {
+    if (!h || !obs_seat || !features_out) return fail(EVG_ERR_INVALID, "bad argument");
+    EVG_ON_DEVICE(h);
+    const int rc = launch_smart_state(h->S, 0, obs_seat, 1, features_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -588,20 +669,8 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         for (int l = 0; l < nlaunch; ++l) {
             io.turns = steps - done_turns < per_launch ? steps - done_turns : per_launch;
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l], s_));
-            const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
+            const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
             if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
-            {   // a chunked launch: remember how many units each XCD's queue holds (evg_episode_stats checks that all were taken)
-                const LaunchPlan pl = plan_step(h->S, io, h->cfg.obs_dtype, h->caps);
-                h->last_chunked_units = 0;
-                const LaunchPiece& cp = pl.piece[pl.n - 1];          // a plan has at most one chunked piece: its last
-                if (cp.chunk_turns > 0) {
-                    const int nsets = (cp.env_hi - cp.env_lo + 31) / 32, nchunks = (io.turns + cp.chunk_turns - 1) / cp.chunk_turns;
-                    for (int x = 0; x < h->S.nxcd; ++x) {
-                        h->last_chunked_units_x[x] = (uint32_t)(((nsets - x + h->S.nxcd - 1) / h->S.nxcd) * nchunks);
-                        h->last_chunked_units += h->last_chunked_units_x[x];
-                    }
-                }
-            }
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l + 1], s_));
             done_turns += io.turns;
         }
@@ -614,6 +683,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
                 tot += ms;
             }
             *step_kernel_ms = (float)(tot / steps);
+            return check_fault(h);            // the call has synchronised: a chunk hand-over fault of these launches is reported here
         }
         return EVG_OK;
     }
@@ -633,13 +703,13 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         if (fused) {
             // orders are drawn inside the step kernel
         } else if (random_pair) {
-            rc = launch_random_actions(h->S, actions_buf, stream);
+            rc = launch_random_actions(h->S, actions_buf, -1, stream);
         } else {                                  // the agents read the observations of the previous turn from obs_out
             rc = launch_scripted_actions(h->S, policy0, 0, obs_out, actions_buf, h->cfg.obs_dtype, stream);
             if (!rc) rc = launch_scripted_actions(h->S, policy1, 1, obs_out, actions_buf, h->cfg.obs_dtype, stream);
         }
         if (rc) return fail(EVG_ERR_HIP, "action kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, &h->progress_counter, stream);
+        rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
         if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
     if (step_kernel_ms) {
@@ -648,6 +718,40 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, h->events[0], h->events[1]));
         *step_kernel_ms = ms / (float)steps;
+        return check_fault(h);
+    }
+    return EVG_OK;
+}
+
+int evg_rollout_vs_policy(evg_handle* h, int steps, int seat, int opponent_policy, int32_t* actions_seat_buf, void* obs_seat_out, float* reward_out, uint8_t* done_out,
+                          int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (steps < 1 || !actions_seat_buf || !obs_seat_out || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout_vs_policy: steps >= 1, actions_seat_buf, obs_seat_out, reward_out, done_out required");
+    if (seat < 0 || seat > 1 || opponent_policy < 0 || opponent_policy >= EVG_POLICY_COUNT) return fail(EVG_ERR_INVALID, "seat / opponent_policy out of range");
+    if (((reinterpret_cast<uintptr_t>(obs_seat_out) | reinterpret_cast<uintptr_t>(actions_seat_buf)) & 15u) != 0) return fail(EVG_ERR_INVALID, "obs_seat_out and actions_seat_buf must be 16-byte aligned");
+    if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_rollout_vs_policy: keyed-Philox handles only");
+    EVG_ON_DEVICE(h);
+    hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);
+    while (step_kernel_ms && h->events.size() < 2) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        h->events.push_back(ev);
+    }
+    StepIO io = make_io(h, actions_seat_buf, obs_seat_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 2, opponent_policy, opponent_policy, nullptr);
+    io.seat = seat; io.actions_both = 0;
+    if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[0], s_));
+    for (int i = 0; i < steps; ++i) {
+        int rc = launch_random_actions(h->S, actions_seat_buf, seat, stream);
+        if (!rc) rc = launch_step_seat(h->S, io, h->cfg.obs_dtype, h->caps, stream);
+        if (rc) return fail(EVG_ERR_HIP, "launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    if (step_kernel_ms) {
+        HIP_TRY(hipEventRecord(h->events[1], s_));
+        HIP_TRY(hipStreamSynchronize(s_));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->events[0], h->events[1]));
+        *step_kernel_ms = ms / (float)steps;
+        return check_fault(h);
     }
     return EVG_OK;
 }
@@ -705,6 +809,7 @@ int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
+    { const int frc = check_fault(h); if (frc) return frc; }
     const size_t N = (size_t)h->S.N;
     if (groups) {
         std::vector<uint32_t> g(24 * N), st(6 * N);
@@ -795,20 +900,7 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t)h->S.N;
-    uint32_t fault = 0;
-    HIP_TRY(hipMemcpy(&fault, h->S.fault, sizeof(fault), hipMemcpyDeviceToHost));
-    if (fault) return fail(EVG_ERR_HIP, "a chunked rollout launch failed to hand a set of envs on (fault word %u: 1 = gave up waiting for a predecessor chunk, 2 = a workgroup ran on an "
-                                        "XCD the create-time probe did not see): the results of this handle are not valid", fault);
-    if (h->last_chunked_units) {          // every unit of the last chunked launch was taken from its queue
-        uint32_t qa[1024], q[16];
-        HIP_TRY(hipMemcpy(qa, h->S.queue, sizeof(qa), hipMemcpyDeviceToHost));
-        for (int x = 0; x < 16; ++x) q[x] = qa[x * 64];          // one counter per 256-byte line
-
-        uint64_t taken = 0;
-        for (int x = 0; x < h->S.nxcd; ++x) taken += q[x] < h->last_chunked_units_x[x] ? q[x] : h->last_chunked_units_x[x];
-        if (taken != h->last_chunked_units) return fail(EVG_ERR_HIP, "the last chunked rollout launch played %llu of its %llu units: some XCD ran no workgroup of it",
-                                                       (unsigned long long)taken, (unsigned long long)h->last_chunked_units);
-    }
+    { const int frc = check_fault(h); if (frc) return frc; }
     if (returns) HIP_TRY(hipMemcpy(returns, h->S.fin_ret, 2 * N * sizeof(float), hipMemcpyDeviceToHost));
     if (length) HIP_TRY(hipMemcpy(length, h->S.fin_len, N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (winner) HIP_TRY(hipMemcpy(winner, h->S.fin_win, N, hipMemcpyDeviceToHost));
@@ -824,7 +916,7 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
  *                   CHUNKED form over the whole batch, i.e. with a working set larger than the Infinity Cache), 64 (the two-lanes-per-env kernel at every batch size and in both
  *                   launch forms), 32 (16 envs per wavefront + 32 helper lanes) or 4 (the four-lanes-per-env kernel in both launch forms)
  *   force_ieee_div  != 0: run the step kernel's true-division branch although the table set passed the exact-quotient check */
-int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) {
+EVG_API int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) {
     if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4 && lanes_per_wave != 2)) return fail(EVG_ERR_INVALID, "diag: bad argument");
     EVG_ON_DEVICE(h);
     h->ablate = ablate;
@@ -841,7 +933,7 @@ int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int f
 
 #ifdef EVG_STAMPS
 /* stamps build only: per-workgroup s_memtime stamps of the last step launch, [blocks][16] */
-int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
+EVG_API int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
     if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
@@ -852,7 +944,8 @@ int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
 
 int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen) {
     if (!h || !buf || buflen < 1 || turns_per_launch < 1) return fail(EVG_ERR_INVALID, "launch_plan: bad argument");
-    StepIO io = make_io(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0, nullptr);
+    // the plan of the default rollout: observations written, orders recorded (the pointers are only tested against NULL)
+    StepIO io = make_io(h, nullptr, reinterpret_cast<void*>(16), nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0, reinterpret_cast<int32_t*>(16));
     io.turns = turns_per_launch;
     const LaunchPlan p = plan_step(h->S, io, h->cfg.obs_dtype, h->caps);
     std::string s;
@@ -873,7 +966,8 @@ int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int bu
         else snprintf(tmp, sizeof(tmp), "%s%s<two lanes per env, %s>[envs %d..%d: %d wavefronts of 32 envs]", i ? " + " : "", kname, turns_per_launch > 1 ? "persistent" : "single-turn", pc.env_lo, pc.env_hi, (n + epw - 1) / epw);
         s += tmp;
     }
-    snprintf(tmp, sizeof(tmp), " | device: %d CUs, resident wavefronts two-lane %d, four-lane %d / %d", h->caps.cus, h->caps.slots2, h->caps.slots4_w2, h->caps.slots4_w3);
+    snprintf(tmp, sizeof(tmp), " | device: %d CUs, resident wavefronts two-lane %d, four-lane %d / %d, %d XCDs, Infinity-Cache budget of a launch that cycles through its envs %lld MiB (%lld B per env)", h->caps.cus,
+             h->caps.slots2, h->caps.slots4_w2, h->caps.slots4_w3, h->S.nxcd, (long long)(h->caps.cache_bytes >> 20), rollout_bytes_per_env(io, h->cfg.obs_dtype));
     s += tmp;
     snprintf(buf, (size_t)buflen, "%s", s.c_str());
     return p.n;
@@ -888,8 +982,18 @@ int evg_pack_episode_results(evg_handle* h, float* out, void* stream) {
     return EVG_OK;
 }
 
+int evg_check_fault(evg_handle* h, uint32_t* fault_out) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    EVG_ON_DEVICE(h);
+    HIP_TRY(hipDeviceSynchronize());
+    return check_fault(h, fault_out);
+}
+
 int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    // no synchronisation here (the pointers are handed out once and read on the caller's streams): a fault already seen is reported; one of work still in
+    // flight shows in evg_pack_episode_results' poisoned rows or in evg_check_fault
+    { const int frc = check_fault(h); if (frc) return frc; }
     if (returns) *returns = h->S.fin_ret;
     if (length) *length = h->S.fin_len;
     if (winner) *winner = h->S.fin_win;

@@ -102,10 +102,13 @@ struct DevState {
     uint32_t* mt_pos;            // [N]
     uint32_t  seed_lo, seed_hi, env_id_base;
     const DevTables* T;
-    uint32_t* progress;          // [ceil(N / 32)] chunked persistent launches: set s of 32 envs has finished chunk c of the launch with base b <=> progress[s] == b + c + 1
-    uint32_t* queue;             // [16] chunked launches: next unit of each XCD's queue (zeroed on the stream before every chunked launch)
-    uint32_t* fault;             // [1] bit 0: a wave gave up waiting for a predecessor chunk; bit 1: a workgroup ran on an XCD the create-time probe did not see
-                                 // (never expected; reported by evg_episode_stats)
+    uint32_t* progress;          // [ceil(N / 32)] chunked persistent launches: set s of 32 envs has finished chunk c of the launch <=> progress[s] == c + 1
+    uint32_t* queue;             // [1024] chunked launches: next unit of each XCD's queue, one counter per 256-byte line.  queue and progress are ONE allocation (queue
+                                 // first), zeroed by one memset on the stream before every chunked launch
+    uint32_t* fault;             // [1] bit 0: a wave gave up waiting for a predecessor chunk; bit 1: a workgroup ran on an XCD the create-time probe did not see;
+                                 // bit 2: a queue of a chunked launch was not drained (evg_chunk_verify_kernel, on the stream behind every chunked launch).
+                                 // Never expected; sticky; read by the pack kernel (poisoned rows) and by every host path on which results leave the handle
+    uint32_t* fault_seen;        // [1] host-mapped mirror: set to 1 (plain store) together with any bit of `fault`, so that the host checks cost no device copy
     uint64_t  xcd_rank;          // nibble x = rank of XCC id x among the XCDs of this device (15 = not seen by the probe at evg_create)
     int32_t   nxcd;              // number of XCDs (8 on a whole MI355X)
 };
@@ -127,11 +130,14 @@ struct StepIO {
     int32_t   env_lo, env_hi;    // this launch plays envs [env_lo, env_hi) of the handle (workgroup b: envs env_lo + b * envs-per-wave ...);
                                  // set by launch_step, which may split a batch into several launches (LaunchPlan)
     int32_t   flags;             // STEP_F_*: set by launch_step from the device's capacity (DeviceCaps), not from literals
+    int32_t   seat;              // SEAT instantiation (evg_step_vs_policy / evg_observe_seat): the caller's seat; its 7 rows come from `actions` ([N][7][2], or rows
+                                 // [:, seat] of [N][2][7][2] when actions_both != 0), the other seat's from policy0 / policy1 (gen_actions == 2), and obs is [N][105]
+    int32_t   actions_both;
     int32_t   nsets;             // > 0: CHUNKED persistent launch of the two-lane kernel (batches beyond what the device holds at once): workgroup u
                                  // plays chunk u / nsets (chunk_turns consecutive turns, the last one what is left of `turns`) of env set u % nsets
     int32_t   chunk_turns;
     int32_t   grid_slots;        // workgroups of a chunked launch (what the device holds at once)
-    uint32_t  progress_base;     // value of DevState::progress[set] that means "no chunk of this launch finished yet" (monotonic over launches)
+    uint32_t  progress_base;     // value of DevState::progress[set] that means "no chunk of this launch finished yet" (0: the flags are zeroed before every launch)
 #ifdef EVG_DIAG                  // diagnostic libraries only (libevg_diag.so, libevg_stamps.so)
     int32_t   lanes_per_wave;    // 64: 32 envs per wavefront; 32: 16 envs per wavefront + 32 helper lanes
     uint32_t  ablate;            // bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
@@ -149,7 +155,12 @@ struct DeviceCaps {
     int32_t simds;               // cus x 4
     int32_t slots2;              // resident workgroups (= wavefronts, 32 envs each) of the two-lane step kernel: cus x 8 on MI355X (LDS-bound)
     int32_t slots4_w2, slots4_w3;   // resident wavefronts (16 envs each) of the four-lane kernel built for 2 / 3 waves per SIMD
+    int64_t cache_bytes;         // what a chunked launch may cycle through: this device's share of the memory-side (Infinity) cache -- 256 MiB x cus / 256 on
+                                 // MI355X (HIP has no query for it), or evg_config::cache_mib
 };
+
+// bytes of persistent state per env (evg_state_bytes_per_env): grp, stamp, node, env, episode, health, ep_ret
+constexpr int kStateBytesPerEnv = 24 * 4 + 6 * 4 + 6 * 4 + 4 + 4 + 2 * NU * 8 + 2 * 4;
 
 // One launch of a plan: which kernel plays which envs.
 struct LaunchPiece { int32_t four_lane_wpe; int32_t env_lo, env_hi; int32_t chunk_turns; };   // four_lane_wpe: 0 = two-lane kernel, 2 / 3 = four-lane kernel built for that
@@ -160,14 +171,16 @@ struct LaunchPlan { int32_t n; LaunchPiece piece[2]; };
 int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps);
 int launch_xcd_probe(uint32_t* out /* device [1024] */, void* stream);
 LaunchPlan plan_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps);
-int launch_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps, uint32_t* progress_counter, void* stream);
+long long rollout_bytes_per_env(const StepIO& io, int obs_dtype);
+int launch_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps, void* stream);
+int launch_step_seat(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps, void* stream);
 int launch_reset(const DevState& S, const uint8_t* mask, void* obs, int obs_dtype, void* stream);
-int launch_random_actions(const DevState& S, int32_t* actions, void* stream);
+int launch_random_actions(const DevState& S, int32_t* actions, int seat /* -1: both, [N][2][7][2]; 0 / 1: that seat only, [N][7][2] */, void* stream);
 int launch_scripted_actions(const DevState& S, int policy, int player, const void* obs, int32_t* actions, int obs_dtype, void* stream);
 int launch_scripted_reset(const DevState& S, void* stream);
 int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, int8_t* sight, void* stream);
 int launch_mt_seed(const DevState& S, const uint32_t* seeds_dev, void* stream);
-int launch_smart_state(const DevState& S, int player, const void* obs, float* out, int obs_dtype, void* stream);
+int launch_smart_state(const DevState& S, int player, const void* obs, int seat_only /* obs is [N][105] */, float* out, int obs_dtype, void* stream);
 int launch_pack_results(const DevState& S, float* out, void* stream);
 
 }  // namespace evg

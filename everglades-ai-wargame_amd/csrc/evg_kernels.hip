@@ -177,6 +177,13 @@ __device__ __forceinline__ void zero_columns12(uint32_t (*a)[LPW], int lane, boo
 // value held by the other player's lane of the same env (lane ^ 1): one DPP quad_perm [1,0,3,2] move, no LDS round trip
 __device__ __forceinline__ int xchg1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 
+// The handle's fault word (DevState::fault, sticky) and its host-mapped mirror: the exact bits by a device atomic, "something happened" by a plain
+// system-scope store the host sees after its next synchronisation without a device copy.
+__device__ __forceinline__ void raise_fault(uint32_t* fault, uint32_t* seen, uint32_t bits) {
+    atomicOr(fault, bits);
+    __hip_atomic_store(seen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused env-step: lane = (env slot, player); LPW / 2 envs per wavefront (LPW = 64 is the default variant)
 // ---------------------------------------------------------------------------------------------
@@ -353,10 +360,15 @@ typedef const StepArgs __attribute__((address_space(4))) * step_args_ptr;
 #define S (A->s_)
 #define io (A->io_)
 
-template <typename OT, int LPW, bool MULTI, bool MT = false, bool CHUNKED = false>
+// SEAT (evg_step_vs_policy, evg_observe_seat): the turn of the reference's training / evaluation loops -- a caller on seat io.seat, an on-device bot on the other
+// (evaluate.py:143-152) -- as an instantiation of the single-turn form: the caller's lane takes its 7 rows from the caller's tensor, the other lane evaluates its
+// bot from the on-chip state (the gen_actions == 2 machinery), and only the caller's lane builds an observation row: the wave's image is [32][105] and the
+// write-out half as long.
+template <typename OT, int LPW, bool MULTI, bool MT = false, bool CHUNKED = false, bool SEAT = false>
 __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2))) evg_step_kernel(StepArgs) {
     static_assert(!MT || (!MULTI && LPW == WG), "the stock-entropy mode exists in the single-turn, 32-envs-per-wave form only");
     static_assert(!CHUNKED || (MULTI && LPW == WG && !MT), "the chunked form is an instantiation of the persistent two-lane kernel");
+    static_assert(!SEAT || (!MULTI && !MT && LPW == WG), "the one-seat form is an instantiation of the single-turn two-lane kernel");
     step_args_ptr A = (step_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int EPW = LPW / 2;                        // envs per wavefront
     constexpr int DP_CAP = CombatLds<LPW>::DP_CAP;
@@ -388,7 +400,7 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             q_nx = (io.nsets - q_xi + S.nxcd - 1) / S.nxcd;                           // sets q_xi, q_xi + nxcd, ... are this XCD's
             q_units = q_nx * ((io.turns + io.chunk_turns - 1) / io.chunk_turns);
         } else if (threadIdx.x == 0) {
-            atomicOr(S.fault, 2u);                                                    // a workgroup on an XCD the probe did not see: never expected
+            raise_fault(S.fault, S.fault_seen, 2u);                                   // a workgroup on an XCD the probe did not see: never expected
         }
     }
     STAMP_WAVE_BEGIN();
@@ -412,17 +424,23 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     STAMP(0);
     if (CHUNKABLE && wg_chunk > 0) {
         // wait for the set's previous chunk (relaxed polls that bypass the L1), then ONE agent-scope acquire: it invalidates this CU's L1,
-        // which may still hold lines of this set from an earlier chunk.  The poll is bounded: a wave that gives up flags the handle
-        // (evg_episode_stats reports it) and goes on, so the grid always drains.
+        // which may still hold lines of this set from an earlier chunk.  The wait is bounded IN TIME (s_memrealtime: a constant 100 MHz
+        // counter, so the bound does not depend on the shader clock or on how long a poll takes): a predecessor chunk is ~0.4 ms of work, a
+        // wave that has waited 5 s gives up, flags the handle (fault word: every path on which results leave the handle reports it, the pack
+        // kernel poisons its rows) and goes on, so the grid always drains.
         const uint32_t* flag = S.progress + (e0 >> 5);
         const uint32_t want = io.progress_base + (uint32_t)wg_chunk;
-        int polls = 0;
+        constexpr unsigned long long kGiveUpTicks = 500000000ull;     // 5 s at 100 MHz
+        unsigned long long t_wait0 = 0;
+        bool waiting = false;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++polls > (1 << 21)) {                 // ~ 1 s
-                if (threadIdx.x == 0) atomicOr(S.fault, 1u);
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (!waiting) { waiting = true; t_wait0 = now; }
+            if (now - t_wait0 > kGiveUpTicks) {
+                if (threadIdx.x == 0) raise_fault(S.fault, S.fault_seen, 1u);
                 break;
             }
+            __builtin_amdgcn_s_sleep(16);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -456,7 +474,13 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int2 act_in[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) act_in[i] = make_int2(0, 0);
-    if (!MULTI && !io.gen_actions && io.actions) {
+    if constexpr (SEAT) {                               // the caller's seat: [N][7][2], or its rows of a [N][2][7][2] tensor
+        if (io.actions && P == io.seat) {
+            const int2* ap = reinterpret_cast<const int2*>(io.actions) + (io.actions_both ? ((size_t)e * 2 + P) * NA : (size_t)e * NA);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) act_in[i] = ap[i];
+        }
+    } else if (!MULTI && !io.gen_actions && io.actions) {
         const int2* ap = reinterpret_cast<const int2*>(io.actions) + ((size_t)e * 2 + P) * NA;
 #pragma unroll
         for (int i = 0; i < NA; ++i) act_in[i] = ap[i];
@@ -558,9 +582,14 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
             int pol0 = io.policy0, pol1 = io.policy1;
             asm volatile("" : "+s"(pol0), "+s"(pol1));
             const AgentTabs atabs{L.tab.nib[11], L.tab.nib[12], L.tab.nib[13], T};
-            agent_rows(P ? pol1 : pol0, view, atabs, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, true, status == 0,
+            const bool bot_lane = !SEAT || P != io.seat;        // one-seat form: the caller's lane has no agent (its object is neither consulted nor stored)
+            agent_rows(P ? pol1 : pol0, view, atabs, S.seed_lo, S.seed_hi, S.env_id_base + (uint32_t)e, episode, P, true, status == 0 && bot_lane,
                        &ag_cycle, &ag_swarm, &ag_dfs, act);
-            if (valid && (!MULTI || iter == nturns - 1)) {      // padding lanes of a partial last workgroup never write
+            if constexpr (SEAT) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) act[i] = bot_lane ? act[i] : act_in[i];
+            }
+            if (valid && bot_lane && (!MULTI || iter == nturns - 1)) {      // padding lanes of a partial last workgroup never write
                 const size_t ai_ = (size_t)P * N + e;
                 S.agent_cycle[ai_] = ag_cycle; S.agent_swarm[ai_] = ag_swarm; S.agent_dfs[ai_] = ag_dfs;
             }
@@ -1241,8 +1270,8 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const uint64_t slot_n = P ? L.tab.nib[10] : 0xBA9876543210ull;     // nibble n = board slot of node n in this player's view
     const uint64_t own_n = P ? p1nib : 0xBA9876543210ull;              // nibble n = node n in this player's numbering (:485-486)
     WAVE_SYNC();        // A is dead from here on: the union becomes the output image
-    int16_t* orow = &L.u.O[col * OBS];
-    if (envlane) {
+    int16_t* orow = &L.u.O[(SEAT ? E : col) * OBS];     // one-seat form: the image is [env][105], built by the caller's lane only
+    if (envlane && (!SEAT || P == io.seat)) {
         orow[0] = (int16_t)turn;
 #pragma unroll
         for (int n = 1; n <= NN; ++n) {
@@ -1297,9 +1326,11 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // converts 16 bytes' worth per iteration (conflict-free LDS reads, fully coalesced 1 KiB stores per wave)
     if (want_obs && !ABLATED(16u)) {
         constexpr int EP = 16 / (int)sizeof(OT);          // elements per 16-byte vector
-        constexpr int NVEC = LPW * OBS / EP;
-        const int limit = nvalid * OBS2;
-        OT* out = reinterpret_cast<OT*>(io.obs) + (size_t)e0 * OBS2;
+        constexpr int ROW_E = SEAT ? OBS : OBS2;           // values per env in the output
+        constexpr int NVEC = (LPW / 2) * ROW_E / EP;
+        static_assert((LPW / 2) * ROW_E % EP == 0, "the wave's image is a whole number of 16-byte vectors");
+        const int limit = nvalid * ROW_E;
+        OT* out = reinterpret_cast<OT*>(io.obs) + (size_t)e0 * ROW_E;
         auto unpack = [&](int elem0, int (&vals)[EP]) {
             if constexpr (EP == 4) {
                 const uint2 raw = *reinterpret_cast<const uint2*>(&L.u.O[elem0]);
@@ -1365,11 +1396,28 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (!(CHUNKABLE && io.nsets > 0)) break;
     // publish the chunk to the XCD's other workgroups: every store of this wave (state words, health rows, outputs) has reached the L2
     // they share (s_waitcnt vmcnt(0); the vector L1 is write-through), then the flag.  No L2 write-back: the set never leaves this XCD.
+    // WHAT THIS RELIES ON (it is weaker than an agent-scope release, which the memory model would ask for and which costs a buffer_wbl2 walk
+    // per chunk: 57 % slower, measured): (1) every array of the handle is ordinary coarse-grained device memory (hipMalloc; evg_create
+    // checks the pointer attributes), cached in the L2 of the XCD that touches it; (2) producer and consumer of a set run on the same XCD
+    // (HW_REG_XCC_ID picks the queue), hence share that L2; (3) 128-byte lines that hold words of sets owned by DIFFERENT XCDs (byte-per-env
+    // arrays, ragged N) are only ever merged through byte-masked write-backs of the dirty bytes -- no XCD writes back bytes it did not
+    // write.  The diagnostic library can publish with a real release instead (ablate bit 7) and the parity tests run both.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        bool publish = true;
 #ifdef EVG_DIAG      // fault-path test (ablate bit 6): the first chunk of the launch's first set is never published, its successor must give up and flag the handle
-    if (!(ABLATED(64u) && wg_chunk == 0 && wg_set == 0))
+        publish = !(ABLATED(64u) && wg_chunk == 0 && wg_set == 0);
 #endif
-    if (threadIdx.x == 0) __hip_atomic_store(S.progress + (e0 >> 5), io.progress_base + (uint32_t)wg_chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (publish && threadIdx.x == 0) {
+            uint32_t* const pflag = S.progress + (e0 >> 5);
+            const uint32_t pval = io.progress_base + (uint32_t)wg_chunk + 1u;
+#ifdef EVG_DIAG      // ablate bit 7: publish with an agent-scope release (L2 write-back), what the memory model asks for
+            if (ABLATED(128u)) __hip_atomic_store(pflag, pval, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            else
+#endif
+            __hip_atomic_store(pflag, pval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     WAVE_SYNC();                                         // the next unit's LDS traffic stays behind this one's
     }   // units
 
@@ -1387,8 +1435,21 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ void __launch_bounds__(256) evg_pack_results_kernel(DevState S, float4* __restrict__ out) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= S.N) return;
+    if (*S.fault != 0u) {            // a faulted handle (evg_check_fault) hands out no results: poisoned rows, winner -2 is no EVG_WINNER_* value
+        const float nan = __int_as_float(0x7FC00000);
+        out[e] = make_float4(nan, nan, -2.f, -1.f);
+        return;
+    }
     const float2 r = reinterpret_cast<const float2*>(S.fin_ret)[e];
     out[e] = make_float4(r.x, r.y, (float)S.fin_win[e], (float)S.fin_len[e]);      // small integers are exact in float32
+}
+
+// behind every chunked launch, on its stream: every XCD's queue must have handed out all its units (an XCD that ran no workgroup of the
+// launch would leave its sets unplayed without anybody waiting for them)
+struct ChunkUnits { uint32_t per_xcd[16]; };
+__global__ void __launch_bounds__(WG) evg_chunk_verify_kernel(DevState S, ChunkUnits want) {
+    const int x = threadIdx.x;
+    if (x < S.nxcd && S.queue[x * 64] < want.per_xcd[x]) raise_fault(S.fault, S.fault_seen, 4u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1446,15 +1507,16 @@ __global__ void __launch_bounds__(256) evg_mt_seed_kernel(DevState S, const uint
 // random_actions stand-in (agents/State_Machine/random_actions.py:38-46): 7 distinct groups of 12,
 // 7 distinct nodes of 1..11 per player, partial Fisher-Yates on nibble-packed permutations
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int32_t* actions) {
+__global__ void __launch_bounds__(256) evg_random_actions_kernel(DevState S, int32_t* actions, int seat) {
     // One thread per (env, player) draws its 7 rows; the block's 256 x 56 bytes are contiguous in the output, so they go through LDS and
     // leave as 16-byte-per-lane coalesced stores (a thread's own rows are 56 bytes apart from its neighbour's: direct stores would touch
     // 28 cache lines per instruction).
     __shared__ int2 rows_lds[256 * NA];
+    // seat < 0: both seats, [N][2][7][2]; seat 0 / 1: that seat's rows only, [N][7][2] (one thread per env)
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int total = 2 * S.N;
+    const int total = seat < 0 ? 2 * S.N : S.N;
     if (idx < total) {
-        const int e = idx >> 1, p = idx & 1;
+        const int e = seat < 0 ? idx >> 1 : idx, p = seat < 0 ? idx & 1 : seat;
         const int turn = (int)(S.env[e] & 0xFFu);
         const uint32_t episode = S.episode[e];
         const uint32_t env_id = S.env_id_base + (uint32_t)e;
@@ -1558,7 +1620,7 @@ __global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* fog, 
 // rounded once).
 // ---------------------------------------------------------------------------------------------
 template <typename OT>
-__global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player, const OT* obs, float* out) {
+__global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player, int seat_only, const OT* obs, float* out) {
     // One wavefront per env and pass.  The 105-value observation row is staged in LDS once; every distinct output value of the
     // env goes into a small per-wave table -- the 34 features all swarms share and the 12 per-swarm health features are
     // one IEEE f64 division each (46 lanes: one division sequence per env instead of one per output element), then the
@@ -1581,7 +1643,7 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
     for (int ps = 0; ps < passes; ++ps) {
         const long long e = ((long long)ps * gridDim.x + blockIdx.x) * WPB + w;
         const bool live = e < N;
-        const OT* o = obs + ((size_t)(live ? e : 0) * 2 + player) * OBS;
+        const OT* o = obs + (seat_only ? (size_t)(live ? e : 0) : (size_t)(live ? e : 0) * 2 + player) * OBS;     // seat_only: obs is [N][105]
         row[w][lane] = live ? (int)o[lane] : 0;                              // every observation value is an integer
         row[w][lane + 64] = (live && lane + 64 < OBS) ? (int)o[lane + 64] : 0;
         __syncthreads();
@@ -1701,6 +1763,7 @@ int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps) {
     if (e != hipSuccess) return (int)e;
     caps->cus = prop.multiProcessorCount;
     caps->simds = 4 * caps->cus;
+    caps->cache_bytes = (256ll << 20) * caps->cus / 256;      // MI355X: 256 MiB of Infinity Cache behind 256 CUs; a partition gets its share (evg_config::cache_mib overrides)
     switch (obs_dtype) {
         case EVG_OBS_F32: return query_caps_t<float>(caps);
         case EVG_OBS_F64: return query_caps_t<double>(caps);
@@ -1728,10 +1791,17 @@ int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps) {
 #define EVG_CHUNK_TURNS 25                 // turns per chunk of a chunked launch (a build-time knob so that it can be re-measured with two builds: tools/scaling_lib.py)
 #endif
 [[maybe_unused]] constexpr int kChunkTurns = EVG_CHUNK_TURNS;
-// A chunked launch cycles through ALL its envs every few chunks, so its working set -- state, observations, orders, results: 2.76 KB per
-// env with float32 observations -- must fit the Infinity Cache (256 MiB on MI355X; HIP has no query for it): measured, us per turn,
-// chunked / the alternative: 98 304 envs (271 MB) 25.8 / 27.5; 104 448 envs (288 MB) 32.5 / ~29.5.
-[[maybe_unused]] constexpr long long kChunkFootprintMax = (256ll << 20) + (256ll << 20) / 50;
+// A chunked launch cycles through ALL its envs every few chunks, so its working set -- state, and what THIS rollout writes: observations,
+// orders, results; 2.74 KB per env with float32 observations -- must fit the device's share of the Infinity Cache (DeviceCaps::cache_bytes:
+// 256 MiB on a whole MI355X, + 2 %): measured, us per turn, chunked / the alternative: 98 304 envs (270 MB) 25.8 / 27.5; 104 448 envs
+// (287 MB) 32.5 / ~29.5.
+long long rollout_bytes_per_env(const StepIO& io, int obs_dtype) {
+    long long b = kStateBytesPerEnv + 13 /* fin_ret, fin_len, fin_win */ + 19 /* reward, done, winner, scores, status */;
+    if (io.obs) b += OBS2 * (obs_dtype == EVG_OBS_F64 ? 8 : (obs_dtype == EVG_OBS_I16 ? 2 : 4));
+    if (io.actions_out) b += 2 * NA * 2 * 4;
+    if (io.gen_actions == 2) b += 24;                    // the scripted agents' objects
+    return b;
+}
 LaunchPlan plan_step(const DevState& S, const StepIO& io, int obs_dtype, const DeviceCaps& caps) {
     LaunchPlan p;
     p.n = 1;
@@ -1756,8 +1826,7 @@ LaunchPlan plan_step(const DevState& S, const StepIO& io, int obs_dtype, const D
     if (N <= cap2) return p;
     const long long full = N / cap2, rem = N - full * cap2;
     if (rem == 0) return p;                         // whole rounds only: one plain launch
-    const long long bytes_per_env = 1773 + 210 * (obs_dtype == EVG_OBS_F64 ? 8 : (obs_dtype == EVG_OBS_I16 ? 2 : 4)) + 112 + 32;
-    if ((cap2 + rem) * bytes_per_env <= kChunkFootprintMax && io.turns > kChunkTurns) {
+    if ((cap2 + rem) * rollout_bytes_per_env(io, obs_dtype) <= caps.cache_bytes + caps.cache_bytes / 50 && io.turns > kChunkTurns) {
         p.n = 0;
         if (full >= 2) p.piece[p.n++] = LaunchPiece{0, 0, (int32_t)((full - 1) * cap2), 0};
         p.piece[p.n++] = LaunchPiece{0, (int32_t)((full - 1) * cap2), (int32_t)N, kChunkTurns};
@@ -1770,7 +1839,7 @@ LaunchPlan plan_step(const DevState& S, const StepIO& io, int obs_dtype, const D
 #endif
 }
 
-int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const DeviceCaps& caps, uint32_t* progress_counter, void* stream) {
+int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const DeviceCaps& caps, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     StepIO io = io_in;
     const bool multi = io.turns > 1;
@@ -1801,13 +1870,14 @@ int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const Dev
         io.env_lo = pc.env_lo; io.env_hi = pc.env_hi;
         io.flags = (pc.four_lane_wpe && (pc.env_hi - pc.env_lo + 15) / 16 > caps.simds) ? STEP_F_SHARED_SIMD : 0;
         io.nsets = 0; io.chunk_turns = 0;
-        if (pc.chunk_turns > 0 && progress_counter) {
+        if (pc.chunk_turns > 0) {
             io.nsets = (pc.env_hi - pc.env_lo + WG / 2 - 1) / (WG / 2);
             io.chunk_turns = pc.chunk_turns;
-            io.progress_base = *progress_counter;
-            *progress_counter += (uint32_t)((io.turns + pc.chunk_turns - 1) / pc.chunk_turns) + 1u;     // the flags of this launch end at base + chunks
+            io.progress_base = 0;
             io.grid_slots = io.nsets < caps.slots2 ? io.nsets : caps.slots2;
-            const hipError_t me = hipMemsetAsync(S.queue, 0, 1024 * sizeof(uint32_t), s);               // every XCD's queue starts at unit 0
+            // every XCD's queue starts at unit 0 and every set's progress flag at "no chunk finished": ONE memset on the stream (the two arrays are one
+            // allocation, queue first).  Nothing of a chunked launch lives on the host, so a captured launch can be replayed (hipGraph).
+            const hipError_t me = hipMemsetAsync(S.queue, 0, (1024 + ((size_t)S.N + 31) / 32 + 1) * sizeof(uint32_t), s);
             if (me != hipSuccess) return (int)me;
         }
         int rc;
@@ -1816,8 +1886,36 @@ int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const Dev
         else if (io.nsets > 0) rc = launch_step_chunked(S, io, obs_dtype, s);
         else rc = launch_step_variant<64, true>(S, io, obs_dtype, s);
         if (rc) return rc;
+        if (io.nsets > 0) {
+            // ... and behind it, on the same stream: every XCD's queue handed out all its units (sets x chunks), or the handle is flagged
+            ChunkUnits want;
+            const uint32_t nchunks = (uint32_t)((io.turns + io.chunk_turns - 1) / io.chunk_turns);
+            for (int x = 0; x < 16; ++x) want.per_xcd[x] = x < S.nxcd ? (uint32_t)((io.nsets - x + S.nxcd - 1) / S.nxcd) * nchunks : 0u;
+            hipLaunchKernelGGL(evg_chunk_verify_kernel, dim3(1), dim3(WG), 0, s, S, want);
+            rc = (int)hipGetLastError();
+            if (rc) return rc;
+        }
     }
     return 0;
+}
+
+// evg_step_vs_policy / evg_observe_seat: one launch of the one-seat instantiation of the single-turn two-lane kernel
+int launch_step_seat(const DevState& S, const StepIO& io_in, int obs_dtype, const DeviceCaps& caps, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (S.mt_key) return -1;
+    StepIO io = io_in;
+    io.turns = 1; io.env_lo = 0; io.env_hi = S.N; io.flags = 0; io.nsets = 0; io.chunk_turns = 0; io.progress_base = 0; io.grid_slots = 0;
+    const int grid2 = (S.N + WG / 2 - 1) / (WG / 2);
+    if (grid2 <= caps.slots2) io.flags |= STEP_F_STAGGER;
+    const dim3 grid(grid2), block(WG);
+    const StepArgs args{S, io};
+    switch (obs_dtype) {
+        case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, WG, false, false, false, true>), grid, block, 0, s, args); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, WG, false, false, false, true>), grid, block, 0, s, args); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, WG, false, false, false, true>), grid, block, 0, s, args); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
 }
 
 // which XCC ids does this device have?  (evg_create: 1 024 one-wave workgroups report where they ran)
@@ -1863,14 +1961,14 @@ int launch_scripted_reset(const DevState& S, void* stream) {
     return (int)hipGetLastError();
 }
 
-int launch_smart_state(const DevState& S, int player, const void* obs, float* out, int obs_dtype, void* stream) {
+int launch_smart_state(const DevState& S, int player, const void* obs, int seat_only, float* out, int obs_dtype, void* stream) {
     const int blocks = (S.N + 3) / 4;                       // one wavefront per env and pass; 8 blocks per CU resident, further envs in passes
     const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (obs_dtype) {
-        case EVG_OBS_F32: hipLaunchKernelGGL(evg_smart_state_kernel<float>, grid, block, 0, s, S.N, player, (const float*)obs, out); break;
-        case EVG_OBS_F64: hipLaunchKernelGGL(evg_smart_state_kernel<double>, grid, block, 0, s, S.N, player, (const double*)obs, out); break;
-        case EVG_OBS_I16: hipLaunchKernelGGL(evg_smart_state_kernel<int16_t>, grid, block, 0, s, S.N, player, (const int16_t*)obs, out); break;
+        case EVG_OBS_F32: hipLaunchKernelGGL(evg_smart_state_kernel<float>, grid, block, 0, s, S.N, player, seat_only, (const float*)obs, out); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL(evg_smart_state_kernel<double>, grid, block, 0, s, S.N, player, seat_only, (const double*)obs, out); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL(evg_smart_state_kernel<int16_t>, grid, block, 0, s, S.N, player, seat_only, (const int16_t*)obs, out); break;
         default: return -1;
     }
     return (int)hipGetLastError();
@@ -1886,9 +1984,9 @@ int launch_pack_results(const DevState& S, float* out, void* stream) {
     return (int)hipGetLastError();
 }
 
-int launch_random_actions(const DevState& S, int32_t* actions, void* stream) {
-    const dim3 grid((2 * S.N + 255) / 256), block(256);
-    hipLaunchKernelGGL(evg_random_actions_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), S, actions);
+int launch_random_actions(const DevState& S, int32_t* actions, int seat, void* stream) {
+    const dim3 grid(((seat < 0 ? 2 : 1) * S.N + 255) / 256), block(256);
+    hipLaunchKernelGGL(evg_random_actions_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), S, actions, seat);
     return (int)hipGetLastError();
 }
 

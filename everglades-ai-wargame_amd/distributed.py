@@ -138,6 +138,7 @@ class ResultGather:
         actually carried from each rank (bench.py reports it for N > 1)."""
         out, at = [], 0
         w = full[:, 2].to("cpu")
+        _refuse_poisoned(w)
         for c in self.counts:
             out.append(int((w[at:at + c] >= 0).sum()))
             at += c
@@ -152,10 +153,19 @@ class ResultGather:
     @staticmethod
     def win_counts(full):
         w = full[:, 2].to("cpu")
+        _refuse_poisoned(w)
         return (int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum()))
+
+
+def _refuse_poisoned(w):
+    """Rows with winner -2 come from a handle whose fault word is set (evg_pack_episode_results poisons them): its results are not valid."""
+    if bool((w == -2).any()):
+        from ._lib import EvgFault
+        raise EvgFault("%d gathered rows are poisoned (winner -2): a rank's handle reported a chunk hand-over fault (evg_check_fault); its results are not valid" % int((w == -2).sum()))
 
 
 def win_counts(gathered):
     """(p0 wins, p1 wins, ties, envs without a finished episode) of a gather_episode_results() result."""
     w = gathered["winner"].to("cpu")
+    _refuse_poisoned(w)
     return (int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum()))

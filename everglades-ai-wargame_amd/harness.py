@@ -7,7 +7,10 @@ The games run as `num_envs` concurrent envs on the GPU, `episodes / num_envs` co
 reference's agent objects, which are built once outside the episode loop (evaluate.py:85-93), the on-device scripted
 agents keep their state across the consecutive episodes of an env.  Agents are the on-device bots of
 agents/State_Machine/ (by file name, see EvergladesVecEnv.scripted_actions) or a callable `policy(obs) -> actions` that
-maps the observation tensor [N, 2, 105] to this seat's orders, an int32 tensor [N, 7, 2] on the same device.
+maps ITS SEAT's observations [N, 105] -- the batched `players[p].get_action(obs[p])` of evaluate.py:143-147 -- to this seat's
+orders, an int32 tensor [N, 7, 2] on the same device.  The case every script of the reference runs, one callable (the
+learner) against one on-device bot, takes ONE launch per turn (EvergladesVecEnv.step_vs -> evg_step_vs_policy: the bot is
+evaluated inside the step kernel and only the learner's observation is written).
 """
 import math
 
@@ -61,14 +64,21 @@ def evaluate(player0, player1, episodes, num_envs=4096, seed=0, device=None, alp
         if both_native:
             # finished envs stay frozen; the loop reads only the episode results, so no observations are written and no orders recorded
             env.rollout_policies(max_turns, player0, player1, fused=True, turns_per_launch=turns_per_launch, observe=False, record_actions=False)
+        elif _is_device_policy(player0) != _is_device_policy(player1):
+            # a learner on one seat, an on-device bot on the other: one launch per turn, the learner's observation only
+            seat = 1 if _is_device_policy(player0) else 0
+            learner, bot = (player0, player1) if seat == 0 else (player1, player0)
+            seat_obs = env.observe_seat(seat)
+            for _t in range(max_turns):
+                a = torch.as_tensor(learner(seat_obs), device=env.device).to(torch.int32).reshape(num_envs, 7, 2).contiguous()
+                seat_obs, _, done, _ = env.step_vs(bot, a, seat=seat)
+                if bool(done.all()):
+                    break
         else:
             for _t in range(max_turns):
                 acts = env._actions
                 for seat, pl in ((0, player0), (1, player1)):
-                    if _is_device_policy(pl):
-                        env.scripted_actions(pl, seat)                       # writes this seat's rows of env._actions
-                    else:
-                        acts[:, seat] = torch.as_tensor(pl(obs), device=env.device).to(torch.int32).reshape(num_envs, 7, 2)
+                    acts[:, seat] = torch.as_tensor(pl(obs[:, seat]), device=env.device).to(torch.int32).reshape(num_envs, 7, 2)
                 obs, _, done, _ = env.step(acts)
                 if bool(done.all()):
                     break

@@ -30,12 +30,13 @@ class EvergladesVecEnv(object):
     obs_len = _lib.OBS_LEN
 
     def __init__(self, num_envs, device=None, seed=0, env_id_base=0, obs_dtype="float32", auto_reset=True, tables=None,
-                 map_file=None, unit_file=None, config_dir=None, rng_mode="philox", library=None, diag=None):
+                 map_file=None, unit_file=None, config_dir=None, rng_mode="philox", library=None, diag=None, cache_mib=0):
         """rng_mode "philox" (default, the fast keyed draws of DESIGN.md section 4) or "mt19937": every env owns numpy's legacy
         generator seeded like np.random.seed((seed + env_id_base + e) & 0xFFFFFFFF) and consumes it in the reference's
         order, so a game replays the UNMODIFIED reference process bit for bit (validation mode, sequential draws).
         library / diag: diagnostics only -- path of a diagnostic build of the library (default: the product libevg.so) and, for
-        libevg_diag.so, dict(ablate=bits, lanes=0|64|32|4, force_ieee_div=bool) passed to its evg_diag_configure."""
+        libevg_diag.so, dict(ablate=bits, lanes=0|64|32|4, force_ieee_div=bool) passed to its evg_diag_configure.
+        cache_mib: 0 = derive the memory-side cache budget of chunked rollout launches from the device (evg_config.cache_mib)."""
         torch = _torch()
         self.L = _lib.load(library)
         if not torch.cuda.is_available():
@@ -65,6 +66,7 @@ class EvergladesVecEnv(object):
             raise ValueError("rng_mode must be 'philox' or 'mt19937'")
         self.rng_mode = rng_mode
         cfg.rng_mode = modes[rng_mode]
+        cfg.cache_mib = int(cache_mib)
         cfg.tables = tables
         h = C.c_void_p()
         self._check(self.L.evg_create(C.byref(cfg), C.byref(h)))
@@ -112,6 +114,30 @@ class EvergladesVecEnv(object):
             raise ValueError("%s must be a contiguous %s tensor of shape %s on %s, got %s %s on %s%s" % (
                 name, dtype, tuple(shape), self.device, t.dtype, tuple(t.shape), t.device, "" if t.is_contiguous() else " (not contiguous)"))
         return t
+
+    def _adopt_buffers(self, obs, reward, done, winner, scores, status, actions, obs_seat=None, actions_seat=None):
+        """Use caller-owned tensors (e.g. contiguous slices of full-batch tensors: PipelinedVecEnv) as this env's output / order
+        buffers instead of its own."""
+        torch = _torch()
+        N = self.num_envs
+        self.obs = self._user(obs, (N, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
+        self.reward = self._user(reward, (N, 2), torch.float32, "reward")
+        self.done = self._user(done, (N,), torch.uint8, "done")
+        self.winner = self._user(winner, (N,), torch.int8, "winner")
+        self.scores = self._user(scores, (N, 2), torch.int32, "scores")
+        self.status = self._user(status, (N,), torch.uint8, "status")
+        self._actions = self._user(actions, self._act_shape, torch.int32, "actions")
+        for t in (self.obs, self.reward, self.scores, self._actions):
+            if t.data_ptr() % 16:
+                raise ValueError("adopted buffers must be 16-byte aligned")
+        self._p = {k: C.c_void_p(getattr(self, k).data_ptr()) for k in ("obs", "reward", "done", "winner", "scores", "status", "_actions")}
+        self._info = dict(winner=self.winner, scores=self.scores, status=self.status)
+        if obs_seat is not None:
+            self._obs_seat = self._user(obs_seat, (N, _lib.OBS_LEN), self.obs_dtype, "obs_seat")
+            self._actions_seat = self._user(actions_seat, (N, _lib.NUM_ACTIONS, 2), torch.int32, "actions_seat")
+            if self._obs_seat.data_ptr() % 16 or self._actions_seat.data_ptr() % 16:
+                raise ValueError("adopted buffers must be 16-byte aligned")
+            self._p["obs_seat"] = C.c_void_p(self._obs_seat.data_ptr())
 
     def close(self):
         if getattr(self, "_h", None):
@@ -168,6 +194,69 @@ class EvergladesVecEnv(object):
         self._check(self.L.evg_observe(self._h, self._ptr(self.obs), self._stream()))
         return self.obs
 
+    # ------------------------------------------------------------------ one caller seat against an on-device bot
+    def _seat_buffers(self):
+        torch = _torch()
+        if getattr(self, "_obs_seat", None) is None:
+            with torch.cuda.device(self.device):
+                self._obs_seat = torch.zeros((self.num_envs, _lib.OBS_LEN), dtype=self.obs_dtype, device=self.device)
+                self._actions_seat = torch.zeros((self.num_envs, _lib.NUM_ACTIONS, 2), dtype=torch.int32, device=self.device)
+            self._p["obs_seat"] = C.c_void_p(self._obs_seat.data_ptr())
+        return self._obs_seat
+
+    def step_vs(self, policy, actions, seat=0, out=None):
+        """One turn of the loop the reference's training and evaluation scripts run (evaluate.py:143-152;
+        agents/Smart_State/training_scripts/dqn_smart_state_training.py:114-122): the caller plays `seat` with `actions` -- int32
+        [N, 7, 2], or a [N, 2, 7, 2] tensor whose rows [:, seat] are used --, the on-device scripted bot `policy` (a name from
+        _lib.POLICY_NAMES or an EVG_POLICY_* id) plays the other seat, evaluated INSIDE the step kernel from the on-chip state
+        (evg_step_vs_policy: one launch, no opponent observations or orders through HBM).  Returns (obs_seat [N, 105] -- the caller's
+        seat only --, reward [N, 2], done [N], info) like step(); bit-identical to scripted_actions(policy, 1 - seat) + step()."""
+        torch = _torch()
+        pid = self.POLICIES[policy] if isinstance(policy, str) else int(policy)
+        a = actions
+        if not (type(a) is torch.Tensor and a.dtype is self._int32 and a.device == self.device and a.is_contiguous()):
+            a = torch.as_tensor(actions, device=self.device)
+            a = (a if a.dtype == torch.int32 else a.to(torch.int32)).contiguous()      # truncation, like action.astype(int) (server.py:232)
+        if tuple(a.shape) == self._act_shape:
+            both = 1
+        elif tuple(a.shape) == (self.num_envs, _lib.NUM_ACTIONS, 2):
+            both = 0
+        else:
+            raise ValueError("actions must have shape [N, 7, 2] (the caller's seat) or [N, 2, 7, 2], got %s" % (tuple(a.shape),))
+        obs = self._seat_buffers() if out is None else self._user(out, (self.num_envs, _lib.OBS_LEN), self.obs_dtype, "out")
+        p = self._p
+        rc = self.L.evg_step_vs_policy(self._h, int(seat), C.c_void_p(a.data_ptr()), both, pid, C.c_void_p(obs.data_ptr()), p["reward"], p["done"], p["winner"],
+                                       p["scores"], p["status"], self._stream())
+        if rc:
+            self._check(rc)
+        return obs, self.reward, self.done, self._info
+
+    def rollout_vs(self, steps, policy, seat=0, time_kernel=False):
+        """`steps` turns of the learner-seat loop driven from native code (evg_rollout_vs_policy): per turn the on-device random_actions
+        generator writes the caller seat's rows into a tensor (the stand-in for a policy network's output), then step_vs(policy) runs.
+        Returns like step_vs(); with time_kernel=True also the stream time per turn in ms (synchronises)."""
+        pid = self.POLICIES[policy] if isinstance(policy, str) else int(policy)
+        obs = self._seat_buffers()
+        ms = C.c_float(0.0)
+        p = self._p
+        self._check(self.L.evg_rollout_vs_policy(self._h, int(steps), int(seat), pid, self._ptr(self._actions_seat), p["obs_seat"], p["reward"], p["done"], p["winner"],
+                                                 p["scores"], p["status"], C.byref(ms) if time_kernel else None, self._stream()))
+        out = (obs, self.reward, self.done, self._info)
+        return out + (float(ms.value),) if time_kernel else out
+
+    def observe_seat(self, seat=0, out=None):
+        """obs [N, 105] of one seat from the current state (evg_observe_seat): what a step_vs() loop starts from after reset()."""
+        obs = self._seat_buffers() if out is None else self._user(out, (self.num_envs, _lib.OBS_LEN), self.obs_dtype, "out")
+        self._check(self.L.evg_observe_seat(self._h, int(seat), self._ptr(obs), self._stream()))
+        return obs
+
+    def random_actions_seat(self, seat=0, out=None):
+        """int32 [N, 7, 2]: the rows [:, seat] of random_actions() (a stand-in for a learner's policy output)."""
+        self._seat_buffers()
+        out = self._actions_seat if out is None else self._user(out, (self.num_envs, _lib.NUM_ACTIONS, 2), self._int32, "out")
+        self._check(self.L.evg_random_actions_seat(self._h, int(seat), self._ptr(out), self._stream()))
+        return out
+
     def fog_of_war(self, out=None):
         """uint8 [N, 2, 11]: the fog-of-war mask the reference computes in board_state and discards (server.py:402-425)."""
         torch = _torch()
@@ -209,8 +298,12 @@ class EvergladesVecEnv(object):
         obs = self.obs if obs is None else obs
         if out is None:
             out = torch.empty((self.num_envs, _lib.NUM_GROUPS, 59), dtype=torch.float32, device=self.device)
-        self._user(obs, (self.num_envs, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
         self._user(out, (self.num_envs, _lib.NUM_GROUPS, 59), torch.float32, "out")
+        if isinstance(obs, torch.Tensor) and obs.dim() == 2:          # a one-seat observation tensor [N, 105] (step_vs / observe_seat): `player` is not needed
+            self._user(obs, (self.num_envs, _lib.OBS_LEN), self.obs_dtype, "obs")
+            self._check(self.L.evg_smart_state_seat(self._h, self._ptr(obs), self._ptr(out), self._stream()))
+            return out
+        self._user(obs, (self.num_envs, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
         self._check(self.L.evg_smart_state(self._h, int(player), self._ptr(obs), self._ptr(out), self._stream()))
         return out
 
@@ -253,7 +346,10 @@ class EvergladesVecEnv(object):
         consecutive turns per wavefront, outputs still written every turn).  observe=False / record_actions=False (fused forms only):
         no observations are written (self.obs keeps its old content) / the orders are not stored -- for loops that read only rewards,
         done flags and episode results.  Returns the outputs of
-        the last turn like step(); with time_kernel=True also the average step-kernel time in ms (synchronises)."""
+        the last turn like step(); with time_kernel=True also the STREAM time per turn in ms (synchronises): persistent form -- the duration
+        of each launch (plan) between two events, summed, over the turns played; one launch per turn -- two events around the whole loop,
+        i.e. step kernel + launch gap (+ the action kernel with fused=False).  The kernel alone is in the rocprofv3 traces under profiles/.
+        A timed call also reports a chunk hand-over fault of the handle (EvgFault)."""
         ms = C.c_float(0.0)
         p = self._p                     # cached raw pointers of the env's own buffers: the call itself is the only host work before the launch
         if not fused and not (observe and record_actions):
@@ -363,6 +459,14 @@ class EvergladesVecEnv(object):
             out = self._user(out, (self.num_envs, 4), torch.float32, "out")
         self._check(self.L.evg_pack_episode_results(self._h, self._ptr(out), self._stream()))
         return out
+
+    def check_fault(self):
+        """Synchronises the device and raises EvgFault when the handle's fault word is set (evg_check_fault: a chunked rollout launch failed
+        to hand a set of envs on -- never expected; the handle must then be destroyed).  get_state(), episode_stats(),
+        episode_stats_device() and timed rollouts check it themselves; packed_episode_results() returns poisoned rows (winner -2)."""
+        w = C.c_uint32(0)
+        self._check(self.L.evg_check_fault(self._h, C.byref(w)))
+        return int(w.value)
 
     def launch_plan(self, turns_per_launch=150):
         """(number of kernel launches, description) of what one rollout launch of `turns_per_launch` turns runs for this batch on

@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define EVG_ABI_VERSION 3      /* 3: evg_launch_plan; 2: evg_pack_episode_results and the node words of the state as u32 */
+#define EVG_ABI_VERSION 4      /* 4: evg_step_vs_policy / evg_observe_seat / evg_random_actions_seat / evg_smart_state_seat, evg_check_fault, EVG_ERR_FAULT,
+                                  evg_config.cache_mib, graph-replayed rollouts; 3: evg_launch_plan; 2: evg_pack_episode_results, node words as u32 */
+
+/* The ABI is exactly the functions declared in this header: the library is built with -fvisibility=hidden and only they are exported. */
+#define EVG_API __attribute__((visibility("default")))
 
 /* Fixed dimensions of the reference environment (everglades_env.py:17-22). */
 #define EVG_NUM_PLAYERS 2
@@ -49,7 +53,8 @@ typedef enum evg_status {
     EVG_ERR_INVALID = -1,      /* bad argument / table out of the supported domain */
     EVG_ERR_NO_DEVICE = -2,    /* no usable HIP device (there is no CPU path)        */
     EVG_ERR_HIP = -3,          /* a HIP runtime call failed                         */
-    EVG_ERR_ALLOC = -4
+    EVG_ERR_ALLOC = -4,
+    EVG_ERR_FAULT = -5         /* the handle's fault word is set (evg_check_fault): its results are not valid, destroy it */
 } evg_status;
 
 typedef enum evg_obs_dtype { EVG_OBS_F32 = 0, EVG_OBS_F64 = 1, EVG_OBS_I16 = 2 } evg_obs_dtype;
@@ -111,26 +116,27 @@ typedef struct evg_config {
     int32_t  auto_reset;       /* 1: an env that finishes in step() is reset in the same launch and
                                   obs_out holds the first observation of its next episode           */
     int32_t  rng_mode;         /* evg_rng_mode; in the stock mode env e starts as np.random.seed((uint32)(seed + env_id_base + e)) */
-    int32_t  reserved0;        /* 0 */
+    int32_t  cache_mib;        /* 0 = derive: what a chunked rollout launch may cycle through, in MiB -- the memory-side (Infinity) cache share of this
+                                  device, 256 MiB x compute units / 256 on MI355X (HIP has no query for it); > 0 overrides.  evg_launch_plan reports it */
     evg_tables tables;
 } evg_config;
 
 typedef struct evg_handle evg_handle;
 
 /* Fills `t` with the DemoMap / UnitDefinitions / default-army tables. */
-void evg_default_tables(evg_tables* t);
+EVG_API void evg_default_tables(evg_tables* t);
 
 /* Replaces EvergladesGame.__init__/board_init/unitTypes_init (server.py:14-131): tables are parsed
  * once by the host and copied to the device; state for N envs is allocated and every env is put in
  * the game_init position (episode counter -1, so the first evg_reset starts episode 0). */
-int evg_create(const evg_config* cfg, evg_handle** out);
-void evg_destroy(evg_handle* h);
+EVG_API int evg_create(const evg_config* cfg, evg_handle** out);
+EVG_API void evg_destroy(evg_handle* h);
 
 /* Replaces EvergladesEnv.reset (everglades_env.py:75-116) -> game_init (server.py:133-209) ->
  * _build_observations (everglades_env.py:158-171).
  *   mask    device uint8[N] or NULL (= all): envs with mask != 0 start a new episode
  *   obs_out device [N][2][105] of cfg.obs_dtype or NULL; written for the envs that were reset */
-int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream);
+EVG_API int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream);
 
 /* Replaces EvergladesEnv.step (everglades_env.py:32-73) -> EvergladesGame.game_turn
  * (server.py:211-279: orders, combat :503, movement :656, capture :708, game_end :281) ->
@@ -148,12 +154,31 @@ int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream);
  *   status_out device uint8 [N]  or NULL  (server.py:284-288)
  * Without auto_reset a finished env is frozen: further steps leave it unchanged and repeat its
  * terminal outputs. */
-int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward_out, uint8_t* done_out,
+EVG_API int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward_out, uint8_t* done_out,
              int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream);
 
 /* Observations of the current state without stepping (after evg_set_state, or to re-read them):
  * the board_state/player_state half of step (server.py:382-501). obs_out as in evg_step. */
-int evg_observe(evg_handle* h, void* obs_out, void* stream);
+EVG_API int evg_observe(evg_handle* h, void* obs_out, void* stream);
+
+/* The turn of the loop every training and evaluation script of the reference runs: a caller (the learner) on ONE seat, a scripted
+ * bot on the other (evaluate.py:85-93,143-152: `actions[p] = players[p].get_action(obs[p])` with one learned and one scripted player;
+ * agents/Smart_State/training_scripts/dqn_smart_state_training.py:114-122) -- in ONE launch: the opponent's bot is evaluated inside the
+ * step kernel from the on-chip state (exactly what its observation would hold; same agent objects as evg_scripted_actions, alive across
+ * episodes), the caller's orders are read for the other seat, and only the caller's seat's observation is written (420 B per env less
+ * than evg_step, half of the observation build, no second launch and no round trip of the opponent's observations and orders).
+ *   seat             0 or 1: the caller's seat
+ *   actions          device int32, the caller's 7 order rows per env: [N][7][2] (actions_both_seats == 0) or the rows [:, seat] of
+ *                    a [N][2][7][2] tensor (actions_both_seats != 0; the other seat's rows are ignored).  Domain as in evg_step
+ *   opponent_policy  EVG_POLICY_* played by seat 1 - seat
+ *   obs_seat_out     device [N][105] of cfg.obs_dtype: the caller's seat's observation (everglades_env.py:158-171); 16-byte aligned
+ *   reward_out, done_out, winner_out, scores_out, status_out: as in evg_step (both seats' rewards and scores: the harness compares
+ *                    reward[0] with reward[1], evaluate.py:155-160)
+ * Results are those of evg_scripted_actions(opponent) + evg_step on the same orders, bit for bit.  Keyed-Philox handles only. */
+EVG_API int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out,
+                               float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream);
+/* evg_observe for one seat: obs_seat_out device [N][105] (after evg_reset / evg_set_state, to start a evg_step_vs_policy loop). */
+EVG_API int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream);
 
 /* Fog-of-war planes of the current state, both computed by the reference and never applied to its observations:
  *   fog_out        device uint8 [N][2][11] or NULL: the `valid_nodes` mask of board_state (server.py:402-425);
@@ -163,27 +188,33 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream);
  *                  2 full (controlled, or a non-moving group there), 1 partial (next to a fully controlled OBSERVE node
  *                  of the player, or one of its groups is moving there), 0 none
  * Real node order, not mirrored for player 1, exactly as the reference computes them. */
-int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void* stream);
+EVG_API int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void* stream);
 
 /* The opposing-group sightings `opp_k` of build_knowledge_output (server.py:845-907), also computed and dropped by the
  * reference.  sight_out: device int8 [N][2][12][4]; [e][p][g] = what player p knows of opposing group g:
  *   {seen, node ID, destination key, units alive}.  seen = 1 iff the group is listed at a node whose knowledge level is 1 or 2
  *   and it is either not moving (key -1) or moving to a node of knowledge > 0 (key = that node's index in the node list,
  *   i.e. ID - 1 -- the reference keys stationary groups by -1 and moving ones by the list index, :866-881); else 0,0,0,0. */
-int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream);
+EVG_API int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream);
 
 /* Consumer-side preprocessing of the reference's strongest agent family (agents/Smart_State/DQNAgent.py:200-300,
  * create_swarm_obs): from `player`'s rows of obs (device [N][2][105] of cfg.obs_dtype) to features_out, device float
  * [N][12][59]: per swarm {turn/150, 11 x control/100, 11 x enemy units/100, 11 x idle allied groups/12, one-hot node,
  * avg health x alive / 1000, in transit, one-hot swarm id}; each value is the reference's float64 expression rounded to
  * float32.  evg_move_table fills table[11][5] with Move_Translation.get_move(node0, direction) (host memory). */
-int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream);
-void evg_move_table(int32_t* table);
+EVG_API int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream);
+/* The same features from a one-seat observation tensor (device [N][105], as evg_step_vs_policy / evg_observe_seat write it). */
+EVG_API int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_out, void* stream);
+EVG_API void evg_move_table(int32_t* table);
 
 /* Input generator for the benchmark configs: the on-device equivalent of
  * agents/State_Machine/random_actions.py:38-46 for every env and both players, keyed by
  * (seed, env id, episode, turn, player).  actions_out: device int32 [N][2][7][2]. */
-int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream);
+EVG_API int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream);
+
+/* The same generator for ONE seat: actions_seat_out device int32 [N][7][2], identical to the rows [:, seat] of evg_random_actions
+ * (a stand-in for a learner's policy output in benchmarks of evg_step_vs_policy). */
+EVG_API int evg_random_actions_seat(evg_handle* h, int seat, int32_t* actions_seat_out, void* stream);
 
 /* Scripted opponents on the device (agents/State_Machine/): one agent object per (env, player), kept in the handle
  * and alive across episodes like the reference's (evaluate.py:85-93).  Reads `player`'s rows of obs (device
@@ -214,8 +245,8 @@ enum {
     EVG_POLICY_SAME_COMMANDS = 14,         /* same_commands.py, same_commands_2.py                           */
     EVG_POLICY_COUNT = 15
 };
-int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream);
-int evg_scripted_reset(evg_handle* h, void* stream);
+EVG_API int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream);
+EVG_API int evg_scripted_reset(evg_handle* h, void* stream);
 
 /* Rollout driver for random-vs-random play (the reference's demo/random_demo.py:90-113 loop with both
  * agents = random_actions): enqueues `steps` x (evg_random_actions into actions_buf, then evg_step) on
@@ -233,7 +264,7 @@ int evg_scripted_reset(evg_handle* h, void* stream);
  * stream time per turn in milliseconds: persistent form -- the duration of each launch (or launch plan, see
  * evg_launch_plan), summed, over the turns played; one launch per turn -- two events around the WHOLE loop over `steps`,
  * i.e. the step kernel plus the gap to the next launch plus, with fused == 0, the action kernel of the turn. */
-int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf, void* obs_out, float* reward_out,
+EVG_API int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf, void* obs_out, float* reward_out,
                        uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
                        float* step_kernel_ms, void* stream);
 
@@ -242,9 +273,16 @@ int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf
  * observations when the call starts, e.g. from evg_reset) and one step launch follows.  fused == 1: the step kernel
  * evaluates both agents itself from the on-chip state (the same quantities their observation holds) and stores the
  * orders in actions_buf; fused >= 2: persistent form as in evg_rollout_random.  Identical results in all forms. */
-int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out,
+EVG_API int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out,
                          float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
                          float* step_kernel_ms, void* stream);
+
+/* Driver of the learner-seat loop for benchmarks: `steps` x (evg_random_actions_seat into actions_seat_buf [N][7][2] -- the stand-in for
+ * the caller's policy output arriving in a tensor --, then evg_step_vs_policy(seat, actions_seat_buf, opponent_policy)), enqueued from
+ * native code: two launches per turn.  Outputs and step_kernel_ms (stream time per turn between two events around the whole loop; the
+ * call then synchronises) as in evg_rollout_random with fused == 0. */
+EVG_API int evg_rollout_vs_policy(evg_handle* h, int steps, int seat, int opponent_policy, int32_t* actions_seat_buf, void* obs_seat_out, float* reward_out,
+                                  uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream);
 
 /* Canonical state exchange (host order; used by parity tests and to load golden positions).
  * All pointers are HOST pointers; the call synchronises.  Any pointer may be NULL.
@@ -254,8 +292,8 @@ int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int p
  *   health double[N][2][100]  : unitHealth of the groups back to back         (definitions.py:62)
  *   env    int32 [N][4]       : current_turn, status, episode, reserved
  */
-int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health, int32_t* env);
-int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, const double* health,
+EVG_API int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health, int32_t* env);
+EVG_API int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, const double* health,
                   const int32_t* env);
 
 /* Stock-entropy mode only (EVG_ERR_INVALID otherwise).
@@ -263,9 +301,9 @@ int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, co
  * (uint32)(seed + env_id_base + e)); enqueued on `stream` after a synchronous upload of the seeds.
  * evg_get/set_stock_entropy: the generators themselves, HOST uint32 [N][625] = 624 key words + position (the layout of
  * np.random.get_state()[1:3]); the calls synchronise.  Together with evg_get/set_state this checkpoints a game. */
-int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream);
-int evg_get_stock_entropy(evg_handle* h, uint32_t* out);
-int evg_set_stock_entropy(evg_handle* h, const uint32_t* in);
+EVG_API int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream);
+EVG_API int evg_get_stock_entropy(evg_handle* h, uint32_t* out);
+EVG_API int evg_set_stock_entropy(evg_handle* h, const uint32_t* in);
 
 /* Per-env results of the most recently finished episode, and running totals (device -> host copy,
  * synchronises).  Any pointer may be NULL.
@@ -274,27 +312,37 @@ int evg_set_stock_entropy(evg_handle* h, const uint32_t* in);
  *   winner  int8  [N]     EVG_WINNER_* (NONE if the env has not finished an episode yet)
  *   totals  int64 [4]     episodes finished, p0 wins, p1 wins, ties (this handle, since create)
  */
-int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* winner, int64_t* totals);
+EVG_API int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* winner, int64_t* totals);
+/* The handle's fault word (synchronises the device).  Chunked persistent rollout launches (batches beyond what the device holds at once,
+ * evg_launch_plan) hand sets of envs from workgroup to workgroup; the word records: 1 = a workgroup gave up waiting for a predecessor
+ * chunk (bounded wait, about 5 s), 2 = a workgroup ran on an XCD the create-time probe did not see, 4 = a queue of a chunked launch was
+ * not drained (checked on the stream after every chunked launch).  None is expected ever; all mean that state and results of the
+ * handle are not valid.  The word is STICKY: evg_reset / evg_set_state do not clear it -- destroy the handle.  Returns EVG_OK or
+ * EVG_ERR_FAULT (message in evg_last_error); *fault_out (may be NULL) receives the word.  Every path on which results leave the
+ * handle checks it too: evg_episode_stats, evg_episode_stats_device and evg_get_state fail with EVG_ERR_FAULT, a timed rollout call
+ * (step_kernel_ms != NULL, which synchronises anyway) fails with it, and evg_pack_episode_results writes POISONED rows
+ * {NaN, NaN, -2, -1} for every env (winner -2 is no EVG_WINNER_* value), so a gather of packed rows cannot carry bad results unnoticed. */
+EVG_API int evg_check_fault(evg_handle* h, uint32_t* fault_out);
 /* Device pointers to the same per-env arrays (returns float[N][2], length int32[N], winner int8[N]),
  * for the multi-GPU gather of episode returns without a host round trip. */
-int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner);
+EVG_API int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner);
 /* The same per-env results packed for the path's ONE exchange between GPUs (the win bookkeeping of
  * evaluate.py:155-181 then runs on the gathered rows): out[e] = {return of player 0, return of player 1, winner, length} as
  * float32 (the small integers are exact), 16 bytes per env, written on `stream`.  out: device memory, [N][4], 16-byte aligned. */
-int evg_pack_episode_results(evg_handle* h, float* out, void* stream);
+EVG_API int evg_pack_episode_results(evg_handle* h, float* out, void* stream);
 
 /* Which step kernel(s) a rollout launch of `turns_per_launch` turns runs for this handle's batch on this device, as text in
  * buf (for benchmark records and logs): the kernel mapping (two / four lanes per env), the env range and wavefront count of
  * every launch of the plan, and the device capacity the plan was derived from (compute units from hipDeviceProp_t, resident
  * wavefronts from the kernels' own occupancy -- no 256-CU literal).  turns_per_launch == 1 describes evg_step.  Returns the
  * number of kernel launches per rollout launch (>= 1) or a negative evg_status. */
-int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen);
+EVG_API int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen);
 
-int evg_num_envs(const evg_handle* h);
+EVG_API int evg_num_envs(const evg_handle* h);
 /* bytes of persistent device state per env (for the roofline accounting in DESIGN.md) */
-int evg_state_bytes_per_env(const evg_handle* h);
-const char* evg_last_error(void);
-int evg_abi_version(void);
+EVG_API int evg_state_bytes_per_env(const evg_handle* h);
+EVG_API const char* evg_last_error(void);
+EVG_API int evg_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -191,6 +191,20 @@ def test_product_library_has_no_diagnostic_hooks(evg):
         assert "evg_diag_configure" in subprocess.check_output(["nm", "-D", "--defined-only", evg._lib.DIAG_LIB_PATH], text=True)
 
 
+def test_library_exports_exactly_the_abi(evg):
+    """`nm -D` of the product library lists the entry points of include/evg.h and NOTHING else (-fvisibility=hidden + the version script
+    csrc/evg.map: no C++ launcher, no kernel stub, no host-side kernel handle); the diagnostic library adds only its configure call."""
+    import subprocess
+
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+    assert exported(evg._lib.LIB_PATH) == sorted(evg._lib.EXPORTS)
+    if os.path.exists(evg._lib.DIAG_LIB_PATH):
+        assert exported(evg._lib.DIAG_LIB_PATH) == sorted(evg._lib.EXPORTS + ["evg_diag_configure"])
+
+
 def test_create_rejects_bad_arguments_before_touching_a_device(evg):
     """Argument validation of evg_create that comes before device discovery: wrong struct size / ABI version, no envs, global env
     ids beyond the 32-bit key space of the random streams."""

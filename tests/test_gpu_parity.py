@@ -1447,8 +1447,10 @@ def test_launch_plan_follows_the_device_and_chunked_rollouts_match_oracle(evg, o
 
 def test_a_lost_chunk_hand_over_ends_the_launch_and_is_reported(evg):
     """The safety net of the chunked form: if a set's chunk is never published (simulated through the diagnostic library), the workgroup
-    that took the set's next chunk does not spin for ever -- its poll is bounded (about a second), it flags the handle and plays on, every
-    workgroup leaves when the queues are empty -- and evg_episode_stats reports the fault instead of returning results."""
+    that took the set's next chunk does not spin for ever -- its wait is bounded in time (5 s of s_memrealtime), it flags the handle and
+    plays on, every workgroup leaves when the queues are empty -- and the fault is visible WHEREVER results leave the handle:
+    evg_check_fault, evg_episode_stats, evg_episode_stats_device, evg_get_state and a timed rollout fail with EVG_ERR_FAULT,
+    evg_pack_episode_results (what the multi-GPU gather sends) writes poisoned rows that the win bookkeeping refuses.  The word is sticky."""
     import time
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
@@ -1456,19 +1458,96 @@ def test_a_lost_chunk_hand_over_ends_the_launch_and_is_reported(evg):
     env = evg.EvergladesVecEnv(N, seed=3, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=64))
     assert "chunked" in env.launch_plan(150)[1]
     env.reset()
+    assert env.check_fault() == 0
     t0 = time.perf_counter()
     env.rollout_random(150, turns_per_launch=150)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    assert 0.2 < dt < 20.0, dt                                   # one bounded wait, then the grid drained
-    with pytest.raises(evg.EvgError, match="hand a set of envs on"):
+    assert 3.0 < dt < 30.0, dt                                   # one bounded wait, then the grid drained
+    with pytest.raises(evg.EvgFault, match="hand a set of envs on"):
+        env.check_fault()
+    with pytest.raises(evg.EvgFault, match="hand a set of envs on"):
         env.episode_stats()
+    with pytest.raises(evg.EvgFault):
+        env.episode_stats_device()
+    with pytest.raises(evg.EvgFault):
+        env.get_state()
+    rows = env.packed_episode_results()
+    w = _np(rows)
+    assert (w[:, 2] == -2).all() and np.isnan(w[:, :2]).all() and (w[:, 3] == -1).all()        # poisoned: winner -2 is no EVG_WINNER_* value
+    with pytest.raises(evg.EvgFault, match="poisoned"):
+        evg.ResultGather.win_counts(rows)
+    with pytest.raises(evg.EvgFault, match="poisoned"):
+        evg.win_counts(evg.ResultGather.split(rows))
+    env.reset()                                                  # sticky: a reset does not make the handle valid again
+    with pytest.raises(evg.EvgFault):
+        env.rollout_random(3, turns_per_launch=1, time_kernel=True)        # a timed call synchronises and reports
     env.close()
     ok = evg.EvergladesVecEnv(N, seed=3, auto_reset=True, library=evg._lib.DIAG_LIB_PATH)      # the same library without the knob: no fault
     ok.reset()
-    ok.rollout_random(150, turns_per_launch=150)
+    out = ok.rollout_random(150, turns_per_launch=150, time_kernel=True)
+    assert out[-1] > 0 and ok.check_fault() == 0
     assert ok.episode_stats()["totals"][0] >= N
+    assert (_np(ok.packed_episode_results())[:, 2] >= 0).all()
     ok.close()
+
+
+@pytest.mark.parametrize("variant", ["float64", "int16", "float32-release"])
+def test_chunked_form_other_observation_dtypes_and_a_real_release_vs_oracle(evg, oracle_mod, variant):
+    """The chunked persistent kernel's float64 and int16 instantiations (the write-out template and the launch plan's footprint rule both
+    depend on the dtype): cap2 + 2 048 envs, 160 turns with auto-reset (a 150-turn launch of 6 chunks + a 10-turn launch), every env
+    against the oracle.  Third variant: float32 with the chunk published by an agent-scope RELEASE store (diagnostic library, ablate
+    bit 7) -- what the memory model asks for; the product's cheaper hand-over (csrc/evg_kernels.hip, "WHAT THIS RELIES ON") must give
+    the same result as that and as the oracle."""
+    import torch
+    cap2 = 32 * 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    N, seed, steps = cap2 + 2048, 4242, 160
+    kw = dict(obs_dtype=variant) if variant in ("float64", "int16") else dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=128))
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, **kw)
+    n, text = env.launch_plan(150)
+    assert "chunked" in text and n == 1, text
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset(); ora.reset()
+    env.rollout_random(steps, turns_per_launch=150)
+    for t in range(steps - 1):
+        ora.step_noobs(ora.random_actions())
+    a = ora.random_actions()
+    o_obs, _, _, _ = ora.step(a)
+    assert env.obs.dtype == {"float64": torch.float64, "int16": torch.int16}.get(variant, torch.float32)
+    assert np.array_equal(_np(env._actions), a), "orders of the last turn"
+    _compare_whole_batch(env, ora, o_obs, ("chunked", variant))
+    assert env.check_fault() == 0
+    env.close()
+
+
+def test_chunked_form_under_uneven_load_vs_oracle(evg, oracle_mod):
+    """Hand-overs under UNEVEN load: sets of 32 envs in a planted melee (all 24 groups on node 6: the most expensive turns the game has, two
+    damage-pool passes) alternate with sets in the opening position (no combat for ~10 turns), so the producers of neighbouring sets finish
+    their chunks at very different times and consumers find their predecessor anywhere between long done and still running; every
+    word of every env (state incl. float64 health, observations, episode results) against the oracle after 150 turns with auto-reset."""
+    import torch
+    cap2 = 32 * 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    N, seed = cap2 + 4096 + 13, 77                            # ragged last set
+    melee = ((np.arange(N) // 32) % 3 == 0)
+    g, n, h, e = _melee_state(64, np.arange(64) < 32)            # one melee set + one idle set as templates
+    reps = np.where(melee, np.arange(N) % 32, 32 + np.arange(N) % 32)
+    st0 = (g[reps].copy(), n[reps].copy(), h[reps].copy(), e[reps].copy())
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    assert "chunked" in env.launch_plan(150)[1]
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset(); ora.reset()
+    env.set_state(*st0); ora.set_state(*st0)
+    w = _pool_words(env.get_state()["groups"], 32)
+    assert (w[0::3][:-1] > 1536).all() and (w[1::3] == 0).all()   # every third wavefront starts in the two-pass melee, the others idle
+    env.rollout_random(150, turns_per_launch=150)
+    for t in range(149):
+        ora.step_noobs(ora.random_actions())
+    a = ora.random_actions()
+    o_obs, _, _, _ = ora.step(a)
+    assert np.array_equal(_np(env._actions), a)
+    _compare_whole_batch(env, ora, o_obs, "chunked, uneven load")
+    assert env.check_fault() == 0
+    env.close()
 
 
 def test_rollouts_without_observations_play_the_same_games(evg, oracle_mod):
@@ -1510,3 +1589,220 @@ def test_rollouts_without_observations_play_the_same_games(evg, oracle_mod):
         e = evg.EvergladesVecEnv(64, seed=1)
         e.reset()
         e.rollout_random(3, fused=False, observe=False)
+
+
+def _wild_seat_rows(rng, N):
+    """[N, 7, 2] orders with out-of-domain / duplicate / negative ids (the `wild` policy's ingredients) mixed into valid ones"""
+    a = np.stack([rng.integers(-13, 13, size=(N, 7)), rng.integers(-13, 13, size=(N, 7))], axis=-1).astype(np.int32)
+    plain = np.stack([rng.integers(0, 12, size=(N, 7)), rng.integers(1, 12, size=(N, 7))], axis=-1).astype(np.int32)
+    return np.where(rng.random((N, 1, 1)) < 0.3, a, plain)
+
+
+@pytest.mark.parametrize("pol", list(range(15)))
+def test_step_vs_policy_every_bot_both_seats_vs_oracle(evg, oracle_mod, pol):
+    """evg_step_vs_policy -- the loop every training / evaluation script of the reference runs: a caller on one seat, a scripted bot
+    on the other (evaluate.py:143-152; dqn_smart_state_training.py:114-122) -- for all 15 bots on both seats at 1 000 envs with
+    auto-reset, 230 turns (agents alive across episodes): the caller's orders are random rows with out-of-domain ids mixed in; the
+    caller's observation, rewards, scores, done flags every turn and the final state == oracle (scripted_actions for the bot's seat
+    from ITS observation + step).  The caller's rows arrive as [N, 7, 2] in one seat and as rows of a [N, 2, 7, 2] tensor in the other."""
+    import torch
+    N, steps = 1000, 230
+    for seat in (0, 1):
+        seed = 7000 + 10 * pol + seat
+        rng = np.random.default_rng(seed)
+        env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+        ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+        env.reset()
+        o_obs = ora.reset()
+        assert np.array_equal(_np(env.observe_seat(seat)).astype(np.float64), o_obs[:, seat])
+        both = torch.zeros((N, 2, 7, 2), dtype=torch.int32, device=env.device)
+        for t in range(steps):
+            rows = _wild_seat_rows(rng, N)
+            oa = np.zeros((N, 2, 7, 2), np.int32)
+            ora.scripted_actions(pol, 1 - seat, o_obs, oa)
+            oa[:, seat] = rows
+            if seat == 0:
+                obs, rew, done, info = env.step_vs(pol, torch.as_tensor(rows, device=env.device), seat=seat)
+            else:
+                both[:, seat] = torch.as_tensor(rows, device=env.device)
+                both[:, 1 - seat] = -7                           # the other seat's rows of the tensor are ignored
+                obs, rew, done, info = env.step_vs(pol, both, seat=seat)
+            o_obs, o_rew, o_done, o_info = ora.step(oa)
+            assert obs.shape == (N, 105)
+            assert np.array_equal(_np(obs).astype(np.float64), o_obs[:, seat]), ("obs", pol, seat, t)
+            assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(done), o_done), (pol, seat, t)
+            assert np.array_equal(_np(info["winner"]), o_info["winner"]) and np.array_equal(_np(info["status"]), o_info["status"])
+            assert np.allclose(_np(rew), o_rew, rtol=0, atol=1e-6)
+        check_state(env, ora.get_state(), ("step_vs", pol, seat))
+        st, ost = env.episode_stats(), ora.episode_stats()
+        assert np.array_equal(st["totals"], ost["totals"]) and np.array_equal(st["winner"], ost["winner"]) and st["totals"][0] >= N
+        env.close()
+
+
+@pytest.mark.parametrize("pol,seat,dtype", [("swarm", 0, "float32"), ("cycle_rush_turn25", 1, "float32"), ("swarm", 1, "float64"), ("cycle_rush_turn25", 0, "int16")])
+def test_step_vs_policy_whole_batch_vs_oracle(evg, oracle_mod, pol, seat, dtype):
+    """evg_step_vs_policy at the headline size: 65 536 envs + a ragged tail, 200 turns with auto-reset, the caller's orders from the
+    on-device generator (evg_random_actions_seat == the seat's rows of evg_random_actions); every env's state incl. float64 health, the
+    caller's observation and the episode results against the oracle; all three observation dtypes across the cases."""
+    import torch
+    N, seed, steps = 65536 + 37, 31337 + seat, 200
+    pid = evg.EvergladesVecEnv.POLICIES[pol]
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, obs_dtype=dtype)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset()
+    o_obs = ora.reset()
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(steps):
+        a = env.random_actions_seat(seat)
+        if t in (0, 57, steps - 1):
+            assert torch.equal(a, env.random_actions()[:, seat])
+        ora.scripted_actions(pid, 1 - seat, o_obs, oa)
+        oa[:, seat] = ora.random_actions()[:, seat]
+        if t in (0, 57, steps - 1):
+            assert np.array_equal(_np(a), oa[:, seat])
+        obs, rew, done, info = env.step_vs(pol, a, seat=seat)
+        o_obs, _, _, _ = ora.step(oa)
+    assert np.array_equal(_np(obs).astype(np.float64), o_obs[:, seat]), "caller's observation"
+    s, os_ = env.get_state(), ora.get_state()
+    for k in ("groups", "nodes", "health", "env"):
+        assert np.array_equal(s[k], os_[k]), (k, int((s[k] != os_[k]).reshape(N, -1).any(axis=1).sum()), "envs differ")
+    st, ost = env.episode_stats(), ora.episode_stats()
+    assert np.array_equal(st["winner"], ost["winner"]) and np.array_equal(st["length"], ost["length"]) and np.array_equal(st["totals"], ost["totals"])
+    assert st["totals"][0] >= N
+    # the full observation of the same state and the one-seat one agree; smart-state features from the one-seat tensor == from the full one
+    full = env.observe()
+    assert torch.equal(full[:, seat], env.observe_seat(seat))
+    assert torch.equal(env.smart_state(seat), env.smart_state(seat, obs=env.observe_seat(seat)))
+    env.close()
+
+
+def test_step_vs_policy_equals_two_launch_path_without_auto_reset(evg):
+    """evg_step_vs_policy == evg_scripted_actions(bot) + evg_step on the same orders, on frozen (finished, not reset) envs too: a finished
+    game's bot is not consulted and its agent object does not advance; argument validation of the new entry points."""
+    import torch
+    N, seed = 2048, 5
+    a_env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=False)
+    b_env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=False)
+    for seat, pol in ((0, "cycle_rush_turn25"), (1, "cycle_target_node11P2")):
+        a_env.reset(); b_env.reset()
+        a_env.scripted_reset(); b_env.scripted_reset()
+        for t in range(150):
+            rows = a_env.random_actions_seat(seat).clone()
+            oa, _, da, ia = a_env.step_vs(pol, rows, seat=seat)
+            acts = b_env.scripted_actions(pol, 1 - seat)
+            acts[:, seat] = rows
+            ob, _, db, ib = b_env.step(acts)
+            assert torch.equal(oa, ob[:, seat]) and torch.equal(da, db) and torch.equal(ia["scores"], ib["scores"]), (seat, t)
+        sa, sb = a_env.get_state(), b_env.get_state()
+        for k in ("groups", "nodes", "health", "env"):
+            assert np.array_equal(sa[k], sb[k]), k
+        assert bool(a_env.done.any())                            # games did end (time expired at the latest): frozen envs were stepped
+    with pytest.raises(ValueError):
+        a_env.step_vs("swarm", torch.zeros((N, 7), dtype=torch.int32, device=a_env.device))
+    with pytest.raises(evg.EvgError):
+        a_env.step_vs(99, a_env.random_actions_seat(0))
+    with pytest.raises(evg.EvgError):
+        a_env.step_vs("swarm", a_env.random_actions_seat(0), seat=2)
+    mt = evg.EvergladesVecEnv(8, seed=1, rng_mode="mt19937")
+    mt.reset()
+    with pytest.raises(evg.EvgError, match="keyed-Philox"):
+        mt.step_vs("swarm", mt.random_actions_seat(0))
+    mt.close()
+    a_env.close(); b_env.close()
+
+
+def test_evaluate_harness_learner_seat_uses_step_vs(evg):
+    """everglades_amd.evaluate with a callable on one seat and an on-device bot on the other (the reference's evaluate.py with a learned
+    agent against a scripted one) plays the games of the all-native pairing when the callable gives the native bot's orders, on either seat;
+    the callable receives ITS seat's observation [N, 105] like players[p].get_action(obs[p])."""
+    import torch
+    N, seed = 96, 21
+    seen = []
+
+    def same_commands(obs):
+        seen.append(tuple(obs.shape))
+        return torch.tensor([[i + 1, i + 1] for i in range(7)], dtype=torch.int32, device=obs.device).expand(N, 7, 2)
+
+    a = evg.evaluate(same_commands, "swarm", N, num_envs=N, seed=seed)
+    b = evg.evaluate("same_commands", "swarm", N, num_envs=N, seed=seed)
+    assert np.array_equal(a["winners"], b["winners"]) and a["mean_length"] == b["mean_length"]
+    c = evg.evaluate("cycle_rush_turn25", same_commands, N, num_envs=N, seed=seed)
+    d = evg.evaluate("cycle_rush_turn25", "same_commands", N, num_envs=N, seed=seed)
+    assert np.array_equal(c["winners"], d["winners"]) and c["mean_length"] == d["mean_length"]
+    assert set(seen) == {(N, 105)}
+
+
+def test_pipelined_halves_equal_one_handle_and_the_oracle(evg, oracle_mod):
+    """PipelinedVecEnv (the double-buffered consumer, everglades_env.py:32-73 called from evaluate.py:143-152): two half-batch handles on
+    two streams with global env ids preserved, driven in the overlapped pattern -- wait for half i, run the 'policy' (the on-device
+    random_actions generator) on the caller's stream, enqueue half i's step on its own stream -- for 300 turns with auto-reset.  The
+    union of the halves equals ONE full handle and the oracle on every env: state incl. float64 health, observations, last orders,
+    episode results."""
+    import torch
+    N, seed, turns = 65536, 99, 300
+    pipe = evg.PipelinedVecEnv(N, pipeline=2, seed=seed, auto_reset=True)
+    assert [r for r in pipe.ranges] == [(0, N // 2), (N // 2, N // 2)]
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    assert np.array_equal(_np(pipe.reset()).astype(np.float64), ora.reset())
+    for t in range(turns):
+        for i in range(pipe.pipeline):
+            obs_i = pipe.wait_part(i)[0]
+            assert obs_i.data_ptr() == pipe.obs[pipe.ranges[i][0]:].data_ptr()       # a view of the full-batch tensor, no copy
+            pipe.step_part(i, pipe.random_actions_part(i))
+    pipe.wait_all()
+    torch.cuda.synchronize()
+    for t in range(turns - 1):
+        ora.step_noobs(ora.random_actions())
+    a = ora.random_actions()
+    o_obs, _, _, _ = ora.step(a)
+    assert np.array_equal(_np(pipe._actions), a), "orders of the last turn"
+    _compare_whole_batch(pipe, ora, o_obs, "pipelined halves")
+    one = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    one.reset()
+    one.rollout_random(turns, turns_per_launch=150)
+    assert torch.equal(one.obs, pipe.obs) and torch.equal(one.reward, pipe.reward) and torch.equal(one.scores, pipe.scores) and torch.equal(one.done, pipe.done)
+    s1, s2 = one.get_state(), pipe.get_state()
+    assert all(np.array_equal(s1[k], s2[k]) for k in s1)
+    one.close()
+    # the free-running benchmark form continues the same games; the joined step() and a masked reset over part boundaries
+    ms = pipe.rollout_random_free(40, time_kernel=True)
+    assert len(ms) == 2 and all(m > 0 for m in ms)
+    for t in range(40):
+        ora.step_noobs(ora.random_actions())
+    a = _np(torch.cat([pipe.random_actions_part(i) for i in range(2)])).copy()
+    obs, rew, done, info = pipe.step(a)
+    o_obs, o_rew, o_done, o_info = ora.step(a)
+    assert np.array_equal(_np(obs).astype(np.float64), o_obs) and np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(done), o_done)
+    mask = (np.arange(N) % 5 == 0).astype(np.uint8)
+    assert np.array_equal(_np(pipe.reset(mask=mask)).astype(np.float64)[mask != 0], ora.reset(mask=mask)[mask != 0])
+    check_state(pipe, ora.get_state(), "pipelined: free-running + joined step + masked reset")
+    pipe.close()
+
+
+def test_pipelined_learner_seat_parts_vs_oracle(evg, oracle_mod):
+    """The overlapped pattern with the learner-seat turn (step_vs_part -> evg_step_vs_policy) on three parts of unequal size, int16
+    observations: the caller's one-seat observation tensor, scores and final state against the oracle."""
+    import torch
+    N, seed, turns, seat, pol = 8192 + 24, 17, 170, 1, "cycle_rush_turn25"
+    pid = evg.EvergladesVecEnv.POLICIES[pol]
+    pipe = evg.PipelinedVecEnv(N, pipeline=3, seed=seed, auto_reset=True, obs_dtype="int16")
+    assert pipe.ranges == [(0, 2752), (2752, 2752), (5504, 2712)]
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    pipe.reset()
+    o_obs = ora.reset()
+    assert np.array_equal(_np(pipe.observe_seat(seat)).astype(np.float64), o_obs[:, seat])
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(turns):
+        for i in range(pipe.pipeline):
+            pipe.wait_part(i, seat=seat)
+            pipe.step_vs_part(i, pol, pipe.random_actions_part(i, seat=seat), seat=seat)
+        ora.scripted_actions(pid, 1 - seat, o_obs, oa)
+        oa[:, seat] = ora.random_actions()[:, seat]
+        o_obs, _, _, o_info = ora.step(oa)
+    pipe.wait_all()
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(pipe.obs_seat).astype(np.float64), o_obs[:, seat]) and np.array_equal(_np(pipe.scores), o_info["scores"])
+    check_state(pipe, ora.get_state(), "pipelined learner seat")
+    st, ost = pipe.episode_stats(), ora.episode_stats()
+    assert np.array_equal(st["totals"], ost["totals"]) and np.array_equal(st["winner"], ost["winner"])
+    pipe.close()

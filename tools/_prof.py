@@ -4,8 +4,10 @@ warm-up launches before them are not part of any reported figure)."""
 import csv, glob, hashlib, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FORMS = {"persistent": ("true, false>", 150, 1), "perturn": ("false, false>", 1, 150),     # kernel-name tail, turns per launch, step launches in the timed window
-         "caller": ("false, false>", 1, 150)}    # caller-supplied orders: per turn the action kernel(s) + the single-turn step kernel
-FORM_KEY = {"persistent": "persistent", "perturn": "one_launch_per_turn", "caller": "caller_actions_per_turn"}
+         "caller": ("false, false>", 1, 150),    # caller-supplied orders: per turn the action kernel(s) + the single-turn step kernel
+         "learner": ("false, false>", 1, 150)}   # learner seat: per turn evg_random_actions_seat + the one-seat instantiation of the single-turn step kernel (evg_step_vs_policy)
+FORM_KEY = {"persistent": "persistent", "perturn": "one_launch_per_turn", "caller": "caller_actions_per_turn", "learner": "learner_vs_bot_per_turn"}
+TWO_KERNEL_FORMS = ("caller", "learner")
 ACTION_KERNELS = ("evg_random_actions_kernel", "evg_scripted_actions_kernel")
 KERNELS_PER_TURN = 1            # of the caller form: set by the summary scripts (2 for random orders, 3 for two scripted agents)
 
@@ -28,11 +30,13 @@ def step_kernel(name, form):
     evg_step4_kernel<OT, MULTI, WPE> (small batches), whichever the run used"""
     dtype = OBS_CTYPE[OBS_DTYPE]
     multi = FORMS[form][0].split(",")[0]
-    if form == "caller" and any(k in name for k in ACTION_KERNELS):
+    if form in TWO_KERNEL_FORMS and any(k in name for k in ACTION_KERNELS):
         return True
     import re
-    # evg_step_kernel<OT, 64, MULTI, MT[, CHUNKED]>: the keyed-draw instantiations (MT = false) of the form's MULTI, plain or chunked
-    if re.search(r"evg_step_kernel<%s, 64, %s, false(, (true|false))?>" % (dtype, multi), name):
+    # evg_step_kernel<OT, 64, MULTI, MT, CHUNKED, SEAT>: the keyed-draw instantiations (MT = false) of the form's MULTI, plain or chunked; the learner form runs SEAT = true
+    if form == "learner":
+        return re.search(r"evg_step_kernel<%s, 64, false, false, false, true>" % dtype, name) is not None
+    if re.search(r"evg_step_kernel<%s, 64, %s, false, (true|false), false>" % (dtype, multi), name):
         return True
     return "evg_step4_kernel<%s, %s" % (dtype, multi) in name
 
@@ -56,7 +60,11 @@ def counter_rows(directory, form):
 def timed_window(rows, form):
     """the dispatches of the timed window: the last 150 turns of the run (one step launch each; in the caller form also the action
     kernel(s) of the turn, KERNELS_PER_TURN dispatches per turn in all)"""
-    return rows[-FORMS[form][2] * (KERNELS_PER_TURN if form == "caller" else 1):]
+    return rows[-FORMS[form][2] * (kernels_per_turn(form)):]
+
+
+def kernels_per_turn(form):
+    return 2 if form == "learner" else (KERNELS_PER_TURN if form == "caller" else 1)
 
 
 def trace_durations(directory, form):

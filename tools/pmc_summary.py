@@ -45,7 +45,7 @@ for form, (tail, tpl, nwin) in FORMS.items():
     f_kb = [r["FETCH_SIZE"] for r in timed_window(fr, form)]
     w_kb = [r["WRITE_SIZE"] for r in timed_window(wr, form)]
     dur = timed_window(trace_durations(os.path.join(P, form + "_stats"), form), form)
-    kpt = _prof.KERNELS_PER_TURN if form == "caller" else 1        # dispatches per launch unit (caller form: action kernel(s) + step kernel = one turn)
+    kpt = _prof.kernels_per_turn(form)                               # dispatches per launch unit (caller / learner forms: action kernel(s) + step kernel = one turn)
     per_launch = (sum(f_kb) / len(f_kb) * round(fetch_scale) + sum(w_kb) / len(w_kb) * round(write_scale)) * 1024.0 * kpt
     mean_ns = sum(dur) / len(dur) * kpt
     bpe = per_launch / tpl / ENVS

@@ -11,10 +11,11 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# FORMS="persistent perturn caller" (default) selects the launch forms; caller = per turn evg_random_actions into a tensor + evg_step(actions)
-for FORM in ${FORMS:-persistent perturn caller}; do
+# FORMS="persistent perturn caller learner" (default) selects the launch forms; caller = per turn evg_random_actions into a tensor + evg_step(actions);
+# learner = per turn evg_random_actions_seat into a tensor + evg_step_vs_policy (bot inside the step kernel, one seat's observation)
+for FORM in ${FORMS:-persistent perturn caller learner}; do
   if [ $FORM = persistent ]; then TPL=150; else TPL=1; fi
-  EXTRA=""; if [ $FORM = caller ]; then EXTRA="--caller-actions"; fi
+  EXTRA=""; if [ $FORM = caller ]; then EXTRA="--caller-actions"; fi; if [ $FORM = learner ]; then EXTRA="--learner-seat"; fi
   CMD="python3 $R/bench.py --steps 150 --warmup 150 --no-cpu-baseline --no-extra-legs --turns-per-launch $TPL $EXTRA $*"
   echo "$CMD" > $OUT/cmd_$FORM.txt
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${FORM}_stats -- $CMD > $OUT/bench_${FORM}_stats.json 2> $OUT/${FORM}_stats.err || exit 1
