@@ -189,6 +189,30 @@ def cpu_baseline(seed, budget_s=12.0):
                        "(BASELINE.md, measured in the build container)" % (n, turns))
 
 
+def expected_if_wire_free(world, steps):
+    """What an N-GPU line should show if the wire cost nothing: N x the committed ONE-rank RCCL rehearsal of the same --steps (process group, pack kernel,
+    gather and all-reduce launches all paid, nothing to transfer), next to the committed plain one-GPU line of the same shape.  None when profiles/
+    holds no such pair.  A first real multi-GPU run is read against this."""
+    def newest(pattern):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+            try:
+                d = json.load(open(f))
+            except Exception:
+                continue
+            if d.get("steps") == steps:
+                return d, os.path.relpath(f, ROOT)
+        return None, None
+    reh, reh_f = newest("*_bench_rehearse_rccl_1rank.json")
+    one, one_f = newest("*_bench_driver_shape.json" if steps == 20 else "*_bench_final.json")
+    if not reh:
+        return None
+    out = {"value_if_wire_free": world * reh["value"], "per_gpu": reh["value"], "from": "1-rank RCCL rehearsal " + reh_f,
+           "collective_us_1rank": (reh.get("distributed") or {}).get("collective_us")}
+    if one:
+        out.update({"one_gpu_value_same_shape": one["value"], "weak_scaling_efficiency_if_wire_free": reh["value"] / one["value"], "one_gpu_from": one_f})
+    return out
+
+
 def _r(x, n=4):
     """numbers of the compact line: n significant digits"""
     if isinstance(x, float):
@@ -227,7 +251,7 @@ def compact_line(full):
     def leg(l):
         if not l:
             return None
-        o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "launches_per_turn", "turns_per_launch") if k in l}
+        o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "launches_per_turn", "turns_per_launch", "parts") if k in l}
         if l.get("roofline"):
             o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("bound", "achieved", "peak", "frac", "bytes_per_env_step", "bytes_source") if l["roofline"].get(k) is not None}
         return o
@@ -242,7 +266,8 @@ def compact_line(full):
                      **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash", "episodes_finished_rank0",
                                           "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
                      "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")),
-                     "learner_vs_bot_per_turn": leg(c.get("learner_vs_bot_per_turn")), "obs_float64": leg(c.get("obs_float64")),
+                     "learner_vs_bot_per_turn": leg(c.get("learner_vs_bot_per_turn")), "pipelined_halves_per_turn": leg(c.get("pipelined_halves_per_turn")),
+                     "obs_float64": leg(c.get("obs_float64")),
                      "without_observations": leg(c.get("without_observations"))}
     out["roofline"] = roof(full["roofline"])
     if "roofline_valu_issue" in full:
@@ -250,7 +275,9 @@ def compact_line(full):
         out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "valu_insts_per_wave_turn", "source")}
     if "distributed" in full:
         d = dict(full["distributed"])
-        d["collective"] = d["collective"].split(" (")[0]
+        d["collective"] = "pack kernel (rows + win counts) + gather to rank 0 + all_reduce of the win counts (= closing barrier)"
+        for k in ("collective_us_is", "closing_bracket"):
+            d.pop(k, None)
         d["per_rank"] = [{k: _r(v, 5) for k, v in r.items()} for r in d.get("per_rank") or []]
         out["distributed"] = d
     if "cpu_baseline" in full:
@@ -283,6 +310,7 @@ def main():
     ap.add_argument("--caller-actions", action="store_true", help="profiling runs: the MAIN leg runs the caller-supplied-actions path (per turn evg_random_actions into a tensor + evg_step); needs --turns-per-launch 1")
     ap.add_argument("--learner-seat", action="store_true", help="profiling runs: the MAIN leg runs the learner-seat path (per turn evg_random_actions_seat into a tensor + evg_step_vs_policy); needs --turns-per-launch 1")
     ap.add_argument("--opponent", default="random", help="the on-device bot of the learner-seat leg (a name from everglades_amd._lib.POLICY_NAMES); random = the headline's game mix")
+    ap.add_argument("--pipeline", type=int, default=2, help="parts of the double-buffered leg (everglades_amd.PipelinedVecEnv)")
     ap.add_argument("--details", default="", help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
     ap.add_argument("--diag-lanes", type=int, default=0, help="diagnostics only: kernel variant of libevg_diag.so (evg_diag_configure lanes)")
@@ -326,12 +354,11 @@ def main():
     first, cnt = evg.shard_range(total, world, rank)
     assert cnt == n_local
 
-    def barrier(closing=False):
-        """barrier + torch.cuda.synchronize().  The closing bracket of the timed region enqueues the barrier's collective right
-        behind the work already on the stream (RCCL orders it after the stream's events) and synchronises once, instead of waking the
-        host twice; the opening bracket drains the device first so that every rank enters the barrier idle."""
-        if not (closing and dist_on and args.backend == "nccl"):
-            torch.cuda.synchronize(device)
+    def barrier():
+        """barrier + torch.cuda.synchronize(): the opening bracket drains the device first so that every rank enters the barrier idle.  (The CLOSING
+        bracket of the N > 1 timed region is the all-reduce of the ranks' win counts -- a barrier that carries the self-check's payload -- followed
+        by one torch.cuda.synchronize(): two RCCL launches behind the step kernels, gather + all-reduce, instead of three.)"""
+        torch.cuda.synchronize(device)
         if dist_on:
             dist.barrier(device_ids=[dev_index]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize(device)
@@ -366,8 +393,11 @@ def main():
     env, rollout = make_env(args.obs_dtype)
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
     gather = evg.ResultGather(n_local, total, device, force=dist_on)   # preallocated buffers; rank 0 receives (one RCCL gather)
-    if dist_on:      # first use opens the RCCL channels: not part of the timed region
-        gather(env.packed_episode_results(out=gather.buffer))
+    win_counts_dev = torch.zeros(4, dtype=torch.int64, device=device)       # filled by the pack kernel: win bookkeeping of this rank's own rows
+    if dist_on:      # first use opens the RCCL channels (gather and all-reduce): not part of the timed region
+        gather(env.packed_episode_results(out=gather.buffer, counts=win_counts_dev))
+        warm = win_counts_dev.clone() if args.backend == "nccl" else win_counts_dev.cpu()
+        dist.all_reduce(warm)
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch, main_fused)
         played += args.warmup
@@ -378,27 +408,41 @@ def main():
     t0 = time.perf_counter()
     gathered = None
     if not dist_on:
-        kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch, main_fused)      # HIP events around the step-kernel launches, read after the last one
-    else:
-        # nothing between the launches and the collective waits for the host: the step kernels, the pack kernel and the gather are
-        # enqueued back to back on the stream; the launches' duration is read from two stream events after the closing barrier
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # the launches are only ENQUEUED here (no event read-out, no synchronisation inside the call); their duration is taken from two stream events after
+        # the closing bracket, so that the bracket's own torch.cuda.synchronize() is the one host wait of the timed region
+        ev0, ev1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
         ev0.record()
         rollout(args.steps, False, args.turns_per_launch, main_fused)
         ev1.record()
-        gathered = gather(env.packed_episode_results(out=gather.buffer))     # one pack kernel + one gather of 16 B per env to rank 0
-    barrier(closing=True)
+    else:
+        # nothing between the launches and the collective waits for the host: the step kernels, the pack kernel and the gather are
+        # enqueued back to back on the stream; the launches' duration is read from two stream events after the closing barrier
+        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        ev0.record()
+        rollout(args.steps, False, args.turns_per_launch, main_fused)
+        ev1.record()
+        gathered = gather(env.packed_episode_results(out=gather.buffer, counts=win_counts_dev))     # one pack kernel (rows + their win counts) + one gather of 16 B per env to rank 0
+        summed_counts = win_counts_dev if args.backend == "nccl" else win_counts_dev.cpu()
+        dist.all_reduce(summed_counts)        # 4 integers per rank: the payload of the self-check below AND the closing barrier of the timed region
+        ev2.record()
+        torch.cuda.synchronize(device)
+    if not dist_on:
+        barrier()
     dt_local = time.perf_counter() - t0
+    collective_ms = None
+    kernel_ms_sum = ev0.elapsed_time(ev1)           # HIP events on the stream the step kernels run on (torch's current stream)
     if dist_on:
-        kernel_ms_sum = ev0.elapsed_time(ev1)
+        collective_ms = ev1.elapsed_time(ev2)
+    if env.check_fault():                           # (never expected: a chunk hand-over fault of a launch plan; raises)
+        raise SystemExit("fault")
     played += args.steps
     dt = dt_local
     per_rank = None
     if dist_on:
-        mine = torch.tensor([dt_local, kernel_ms_sum / args.steps], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        mine = torch.tensor([dt_local, kernel_ms_sum / args.steps, collective_ms * 1e3], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "seconds": float(t[0]), "env_steps_per_s": n_local * args.steps / float(t[0]), "kernel_ms_per_step": float(t[1])}
+        per_rank = [{"rank": r, "seconds": float(t[0]), "env_steps_per_s": n_local * args.steps / float(t[0]), "kernel_ms_per_step": float(t[1]), "collective_us": float(t[2])}
                     for r, t in enumerate(allr)]
         dt = max(p["seconds"] for p in per_rank)
     step_kernel_ms = kernel_ms_sum / args.steps
@@ -409,19 +453,15 @@ def main():
 
     # ---- N > 1: what the collective carried.  Every rank counts the winners of its own rows on its device; the sum over ranks (one
     # all-reduce of 4 integers, outside the timed region) must equal what rank 0 counts in the gathered rows.
+    # (the all-reduce itself closed the timed region: its result is already here)
     dist_check = None
     if dist_on:
-        mine_rows = env.packed_episode_results()
-        w = mine_rows[:, 2]
-        local_counts = torch.stack([(w == 0).sum(), (w == 1).sum(), (w == 2).sum(), (w < 0).sum()]).to(torch.int64)
-        summed = local_counts.clone() if args.backend == "nccl" else local_counts.cpu()
-        dist.all_reduce(summed)
-        dist_check = {"wins_p0_p1_tie_unfinished_sum_over_ranks": [int(x) for x in summed.tolist()]}
+        dist_check = {"wins_p0_p1_tie_unfinished_sum_over_ranks": [int(x) for x in summed_counts.tolist()]}
 
 
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
     # reference's own observation dtype (float64)
-    per_turn_launch = caller_leg = learner_leg = obs_f64 = no_obs_leg = None
+    per_turn_launch = caller_leg = learner_leg = obs_f64 = no_obs_leg = pipe_leg = None
     if world == 1 and not args.no_extra_legs:
         def per_turn_leg(fused):
             """150 turns, one step launch per turn, warmed; wall clock between two barriers and the stream time between two
@@ -457,6 +497,26 @@ def main():
             dq = time.perf_counter() - t1
             no_obs_leg = {"env_steps_per_s": total * 150 / dq, "ms_per_step": dq / 150 * 1e3, "kernel_ms": kq / 150, "turns_per_launch": args.turns_per_launch,
                           "what": "persistent rollout, no observation image / write-out, orders not recorded: rewards, done flags, scores and episode results only"}
+        if main_fused is True and args.workload == "random" and n_local >= 64:
+            # the double-buffered consumer (everglades_amd.PipelinedVecEnv): two half-batch handles on two streams, global env ids preserved, each playing
+            # one launch per turn FREE-RUNNING -- what the overlapped pattern (policy on half A while half B steps) converges to with a cheap policy
+            pipe = evg.PipelinedVecEnv(n_local, pipeline=args.pipeline, device=device, seed=args.seed, env_id_base=first, obs_dtype=args.obs_dtype, auto_reset=True)
+            pipe.reset()
+            phase = episode_phase(torch.arange(first, first + n_local, device=device, dtype=torch.int64))
+            for j in range(PHASES):
+                pipe.rollout_random_free(1)
+                pipe.reset(mask=(phase == j).to(torch.uint8))
+            pipe.rollout_random_free(PHASES, time_kernel=True)
+            barrier()
+            t1 = time.perf_counter()
+            kp = pipe.rollout_random_free(600, time_kernel=True)      # (600 turns: the start of one host thread per part is inside the wall clock)
+            barrier()
+            dp = time.perf_counter() - t1
+            pipe_leg = {"env_steps_per_s": total * 600 / dp, "ms_per_step": dp / 600 * 1e3, "kernel_ms": max(kp), "turns_timed": 600, "parts": args.pipeline, "envs_per_part": [c for _, c in pipe.ranges],
+                        "kernel_ms_is": "stream time per turn of the slowest part (two HIP events around its 600 single-turn launches); ms_per_step is the wall clock per turn of the WHOLE batch",
+                        "stream_ms_per_turn_of_every_part": kp, "launches_per_turn": args.pipeline,
+                        "what": "PipelinedVecEnv.rollout_random_free: every part plays one launch per turn (orders drawn in the step kernel) on its own stream, nothing joins them"}
+            pipe.close()
         if args.obs_dtype != "float64":
             env64, rollout64 = make_env("float64")
             rollout64(8, True, args.turns_per_launch, main_fused)
@@ -505,7 +565,7 @@ def main():
         roof = hbm_roofline(main_form, step_kernel_ms, args.steps / launches)
         n_launch, plan_text = env.launch_plan(tpl)
         roof.update({"kernel": plan_text, "kernel_launches_per_rollout_launch": n_launch, "launch_form": main_form,
-                     "kernel_ms_is": "HIP-event launch duration / turns played by the launch" if tpl > 1 else "stream time per turn (two HIP events around the timed launches)",
+                     "kernel_ms_is": "stream time per turn: two HIP events on the launches' stream around all timed launches / K",
                      "launches_timed": launches, "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch, "launch_ms": launch_ms,
                      "bytes_source_is": "rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction, calibrated in the same passes), per env-step, "
                                         "times the env-steps of the timed launches",
@@ -567,7 +627,7 @@ def main():
                                  "then 150 settle turns, --warmup turns and the K timed turns",
                        "envs_per_gpu": n_local, "total_envs": total, "turns_per_launch": tpl, "turns_of_last_timed_launch": turns_last_launch,
                        "launch_form": main_form,
-                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "learner_vs_bot_per_turn": learner_leg, "obs_float64": obs_f64, "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
+                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "learner_vs_bot_per_turn": learner_leg, "pipelined_halves_per_turn": pipe_leg, "obs_float64": obs_f64, "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
                        "kernel_source_hash": kernel_source_hash(),
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
@@ -586,7 +646,12 @@ def main():
             except Exception as ex:                       # reporting only
                 ver = "unavailable (%s)" % type(ex).__name__
             out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
-                                  "collective": "one pack kernel + torch.distributed.%s of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather), inside the timed region" % gather.collective,
+                                  "collective": "one pack kernel (rows + their win counts) + torch.distributed.%s of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather) + all_reduce of the 4 win counts (= the closing barrier), inside the timed region" % gather.collective,
+                                  "collective_us": max(p["collective_us"] for p in per_rank),
+                                  "collective_us_is": "stream time from the end of the last step launch to the end of the all-reduce (pack kernel, gather, all-reduce), slowest rank",
+                                  "step_launches_us": max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3,
+                                  "closing_bracket": "all_reduce(win counts of every rank's own rows) + torch.cuda.synchronize() -- the barrier of the contract carrying the self-check's payload",
+                                  "expected": expected_if_wire_free(world, args.steps),
                                   "collective_calls": gather.calls, "gathered_rows": int(gathered.shape[0]), "gathered_rows_with_a_finished_episode_per_rank": gather.rows_per_rank(gathered),
                                   "rows_expected_per_rank": gather.counts,
                                   "gathered_wins_equal_sum_of_per_rank_counts": True, "wins_p0_p1_tie_unfinished_sum_over_ranks": dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"],

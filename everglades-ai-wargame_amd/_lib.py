@@ -23,7 +23,7 @@ POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "al
 POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
 EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat", "evg_random_actions_seat", "evg_smart_state_seat", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war", "evg_sightings", "evg_smart_state", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
-           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_launch_plan", "evg_num_envs",
+           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_pack_episode_results_counted", "evg_launch_plan", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
 
@@ -134,6 +134,7 @@ def load(path=None):
     L.evg_episode_stats.argtypes = [vp, vp, vp, vp, vp]
     L.evg_episode_stats_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.evg_pack_episode_results.argtypes = [vp, vp, vp]
+    L.evg_pack_episode_results_counted.argtypes = [vp, vp, vp, vp]
     L.evg_launch_plan.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
     L.evg_num_envs.argtypes = [vp]
     L.evg_state_bytes_per_env.argtypes = [vp]

@@ -74,6 +74,16 @@ struct evg_handle {
     DevTables* d_tables = nullptr;
     DeviceCaps caps;                    // what the device holds at once (query_device_caps at evg_create): drives the launch plan
     uint32_t* fault_seen_host = nullptr;   // host address of DevState::fault_seen (mapped host memory): non-zero <=> some bit of the fault word was set
+    // Rollout launches replayed as hipGraphs (launch_rollout): one executable graph per distinct set of launch arguments, captured once on a
+    // stream of the handle's own (nothing ever runs there) and replayed on the caller's stream with ONE submission per launch plan.
+    struct CachedGraph { StepIO key; hipGraphExec_t exec; };
+    std::vector<CachedGraph> graphs;
+    hipStream_t capture_stream = nullptr;
+#ifdef EVG_NO_GRAPHS                        // A/B builds only (make nograph; tools/ab.sh): every rollout launch enqueued plainly
+    bool graphs_off = true;
+#else
+    bool graphs_off = false;               // a capture or an instantiation failed once: plain launches from then on
+#endif
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
 #ifdef EVG_DIAG                         // diagnostic libraries only, set through evg_diag_configure (never from the environment)
@@ -122,6 +132,57 @@ static int check_fault(evg_handle* h, uint32_t* word_out = nullptr) {
                                           "ran on an XCD the create-time probe did not see, 4 = a queue of a chunked launch was not drained): the state and the results of this handle "
                                           "are not valid; destroy it", fault);
     return EVG_OK;
+}
+
+static bool same_launch(const StepIO& a, const StepIO& b) {
+    bool same = a.actions == b.actions && a.obs == b.obs && a.reward == b.reward && a.done == b.done && a.winner == b.winner && a.scores == b.scores && a.status == b.status &&
+                a.observe_only == b.observe_only && a.gen_actions == b.gen_actions && a.policy0 == b.policy0 && a.policy1 == b.policy1 && a.actions_out == b.actions_out &&
+                a.turns == b.turns && a.seat == b.seat && a.actions_both == b.actions_both;
+#ifdef EVG_DIAG
+    same = same && a.lanes_per_wave == b.lanes_per_wave && a.ablate == b.ablate && a.stamps == b.stamps;
+#endif
+    return same;
+}
+
+static void drop_graphs(evg_handle* h) {
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
+// One launch of a persistent rollout = one launch PLAN (plan_step: up to two step kernels, or memset + chunked kernel + queue check): replayed as a hipGraph.
+// The plan is captured once per distinct argument set on the handle's private stream (capture runs nothing; the caller's stream may be the legacy
+// default stream, which cannot capture), instantiated and kept; every later launch with the same arguments is ONE hipGraphLaunch on the caller's
+// stream instead of up to four submissions.  Everything a launch needs lives on the device (the chunked form zeroes its queues and flags with a
+// memset node), so a replay is exactly the launch.  If the caller's stream is itself capturing (torch.cuda.graph around a rollout call), the
+// kernels are enqueued plainly and become part of the CALLER's graph.
+static int launch_rollout(evg_handle* h, const StepIO& io, hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool caller_captures = s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (h->graphs_off || caller_captures) return launch_step(h->S, io, h->cfg.obs_dtype, h->caps, s);
+    for (auto& g : h->graphs)
+        if (same_launch(g.key, io)) return (int)hipGraphLaunch(g.exec, s);
+    if (!h->capture_stream && hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) != hipSuccess) {
+        h->capture_stream = nullptr; h->graphs_off = true;
+        return launch_step(h->S, io, h->cfg.obs_dtype, h->caps, s);
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal);
+    int rc = 0;
+    if (e == hipSuccess) {
+        rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, h->capture_stream);
+        e = hipStreamEndCapture(h->capture_stream, &graph);
+    }
+    if (e == hipSuccess && !rc) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess || rc) {               // no graph on this runtime: never an error of the rollout itself
+        (void)hipGetLastError();
+        h->graphs_off = true;
+        return launch_step(h->S, io, h->cfg.obs_dtype, h->caps, s);
+    }
+    if (h->graphs.size() >= 16) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
+    h->graphs.push_back({io, exec});
+    return (int)hipGraphLaunch(exec, s);
 }
 
 extern "C" {
@@ -484,6 +545,8 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
 void evg_destroy(evg_handle* h) {
     if (!h) return;
     DeviceGuard guard(h->cfg.device_id);
+    drop_graphs(h);
+    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->fault_seen_host) (void)hipHostFree(h->fault_seen_host);
     for (hipEvent_t ev : h->events) (void)hipEventDestroy(ev);
@@ -669,7 +732,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         for (int l = 0; l < nlaunch; ++l) {
             io.turns = steps - done_turns < per_launch ? steps - done_turns : per_launch;
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l], s_));
-            const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
+            const int rc = launch_rollout(h, io, s_);
             if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l + 1], s_));
             done_turns += io.turns;
@@ -921,6 +984,7 @@ EVG_API int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wav
     EVG_ON_DEVICE(h);
     h->ablate = ablate;
     h->lanes = lanes_per_wave;
+    drop_graphs(h);                        // the knobs are launch arguments of the cached graphs
     if (force_ieee_div) {
         h->host_tables.fast_div = 0;
         h->host_tables.lds.nib[9] &= ~(1ull << 24);
@@ -977,7 +1041,16 @@ int evg_pack_episode_results(evg_handle* h, float* out, void* stream) {
     if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
     if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0) return fail(EVG_ERR_INVALID, "out must be 16-byte aligned");
     EVG_ON_DEVICE(h);
-    const int rc = launch_pack_results(h->S, out, stream);
+    const int rc = launch_pack_results(h->S, out, nullptr, stream);
+    if (rc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t* counts_out, void* stream) {
+    if (!h || !out || !counts_out) return fail(EVG_ERR_INVALID, "null argument");
+    if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0 || (reinterpret_cast<uintptr_t>(counts_out) & 7u) != 0) return fail(EVG_ERR_INVALID, "out must be 16-byte, counts_out 8-byte aligned");
+    EVG_ON_DEVICE(h);
+    const int rc = launch_pack_results(h->S, out, reinterpret_cast<long long*>(counts_out), stream);
     if (rc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }

@@ -1270,7 +1270,10 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const uint64_t slot_n = P ? L.tab.nib[10] : 0xBA9876543210ull;     // nibble n = board slot of node n in this player's view
     const uint64_t own_n = P ? p1nib : 0xBA9876543210ull;              // nibble n = node n in this player's numbering (:485-486)
     WAVE_SYNC();        // A is dead from here on: the union becomes the output image
-    int16_t* orow = &L.u.O[(SEAT ? E : col) * OBS];     // one-seat form: the image is [env][105], built by the caller's lane only
+    // one-seat form: the image is [env][105], built by the caller's lane only.  (Splitting that row between the two lanes of the pair -- half the
+    // instructions -- and the 28 MB less to write change nothing measurable: 26.7 us either way, like evg_step with both rows; a single-turn launch
+    // lasts as long as its slowest SIMD pair, not as long as its instruction or byte count: DESIGN.md section 6.)
+    int16_t* orow = &L.u.O[(SEAT ? E : col) * OBS];
     if (envlane && (!SEAT || P == io.seat)) {
         orow[0] = (int16_t)turn;
 #pragma unroll
@@ -1432,16 +1435,30 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // ---------------------------------------------------------------------------------------------
 // per-env results of the last finished episode, packed for the path's one exchange: 16 bytes per env
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) evg_pack_results_kernel(DevState S, float4* __restrict__ out) {
+__global__ void __launch_bounds__(256) evg_pack_results_kernel(DevState S, float4* __restrict__ out, long long* __restrict__ counts) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= S.N) return;
+    const bool live = e < S.N;
     if (*S.fault != 0u) {            // a faulted handle (evg_check_fault) hands out no results: poisoned rows, winner -2 is no EVG_WINNER_* value
         const float nan = __int_as_float(0x7FC00000);
-        out[e] = make_float4(nan, nan, -2.f, -1.f);
+        if (live) out[e] = make_float4(nan, nan, -2.f, -1.f);
+        if (counts && e < 4) counts[e] = -1;
         return;
     }
-    const float2 r = reinterpret_cast<const float2*>(S.fin_ret)[e];
-    out[e] = make_float4(r.x, r.y, (float)S.fin_win[e], (float)S.fin_len[e]);      // small integers are exact in float32
+    int w = -3;
+    if (live) {
+        const float2 r = reinterpret_cast<const float2*>(S.fin_ret)[e];
+        w = (int)S.fin_win[e];
+        out[e] = make_float4(r.x, r.y, (float)w, (float)S.fin_len[e]);      // small integers are exact in float32
+    }
+    if (counts) {                    // win bookkeeping of these rows (evaluate.py:155-160): one atomic per wavefront and class
+        const unsigned long long m0 = __ballot(w == EVG_WINNER_P0), m1 = __ballot(w == EVG_WINNER_P1), m2 = __ballot(w == EVG_WINNER_TIE), mu = __ballot(live && w < 0);
+        if ((threadIdx.x & 63) == 0) {
+            if (m0) atomicAdd(reinterpret_cast<unsigned long long*>(counts + 0), (unsigned long long)__popcll(m0));
+            if (m1) atomicAdd(reinterpret_cast<unsigned long long*>(counts + 1), (unsigned long long)__popcll(m1));
+            if (m2) atomicAdd(reinterpret_cast<unsigned long long*>(counts + 2), (unsigned long long)__popcll(m2));
+            if (mu) atomicAdd(reinterpret_cast<unsigned long long*>(counts + 3), (unsigned long long)__popcll(mu));
+        }
+    }
 }
 
 // behind every chunked launch, on its stream: every XCD's queue must have handed out all its units (an XCD that ran no workgroup of the
@@ -1979,12 +1996,18 @@ int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, int8_t* sight, vo
     return (int)hipGetLastError();
 }
 
-int launch_pack_results(const DevState& S, float* out, void* stream) {
-    hipLaunchKernelGGL(evg_pack_results_kernel, dim3((S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, reinterpret_cast<float4*>(out));
+int launch_pack_results(const DevState& S, float* out, long long* counts, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (counts) {
+        const hipError_t me = hipMemsetAsync(counts, 0, 4 * sizeof(long long), s);
+        if (me != hipSuccess) return (int)me;
+    }
+    hipLaunchKernelGGL(evg_pack_results_kernel, dim3((S.N + 255) / 256), dim3(256), 0, s, S, reinterpret_cast<float4*>(out), counts);
     return (int)hipGetLastError();
 }
 
 int launch_random_actions(const DevState& S, int32_t* actions, int seat, void* stream) {
+    // (a latency chain of two Philox blocks per thread; 128-thread blocks for the half-sized one-seat form are no faster: 5.4 against 5.2 us)
     const dim3 grid(((seat < 0 ? 2 : 1) * S.N + 255) / 256), block(256);
     hipLaunchKernelGGL(evg_random_actions_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), S, actions, seat);
     return (int)hipGetLastError();

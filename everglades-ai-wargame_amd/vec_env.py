@@ -446,18 +446,25 @@ class EvergladesVecEnv(object):
         return dict(returns=view(pr, (N, 2), torch.float32, 4), length=view(pl, (N,), torch.int32, 4),
                     winner=view(pw, (N,), torch.int8, 1))
 
-    def packed_episode_results(self, out=None):
+    def packed_episode_results(self, out=None, counts=None):
         """The per-env results of the last finished episode as ONE float32 [N, 4] tensor {return p0, return p1, winner, length}
         (evg_pack_episode_results: one small kernel on the current stream): the payload of the path's single exchange between
-        GPUs (`distributed.ResultGather`).  `out`: a float32 [N, 4] CUDA tensor to fill (default: a buffer owned by the env)."""
+        GPUs (`distributed.ResultGather`).  `out`: a float32 [N, 4] CUDA tensor to fill (default: a buffer owned by the env).
+        `counts`: an int64 [4] CUDA tensor that the same kernel fills with the rows' win bookkeeping (p0, p1, ties, unfinished) --
+        what a multi-GPU run all-reduces next to the gather."""
         torch = _torch()
+        if counts is not None:
+            self._user(counts, (4,), torch.int64, "counts")
         if out is None:
             if getattr(self, "_packed", None) is None:
                 self._packed = torch.empty((self.num_envs, 4), dtype=torch.float32, device=self.device)
             out = self._packed
         else:
             out = self._user(out, (self.num_envs, 4), torch.float32, "out")
-        self._check(self.L.evg_pack_episode_results(self._h, self._ptr(out), self._stream()))
+        if counts is not None:
+            self._check(self.L.evg_pack_episode_results_counted(self._h, self._ptr(out), self._ptr(counts), self._stream()))
+        else:
+            self._check(self.L.evg_pack_episode_results(self._h, self._ptr(out), self._stream()))
         return out
 
     def check_fault(self):

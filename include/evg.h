@@ -330,6 +330,10 @@ EVG_API int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** l
  * evaluate.py:155-181 then runs on the gathered rows): out[e] = {return of player 0, return of player 1, winner, length} as
  * float32 (the small integers are exact), 16 bytes per env, written on `stream`.  out: device memory, [N][4], 16-byte aligned. */
 EVG_API int evg_pack_episode_results(evg_handle* h, float* out, void* stream);
+/* The same, and the win bookkeeping of the packed rows in the same kernel: counts_out device int64 [4] = rows with winner P0, P1, TIE and
+ * rows without a finished episode (zeroed and filled on `stream`; all four are -1 when the rows are poisoned).  What a multi-GPU run
+ * all-reduces next to the gather: the sum over ranks must equal what rank 0 counts in the gathered rows (bench.py). */
+EVG_API int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t* counts_out, void* stream);
 
 /* Which step kernel(s) a rollout launch of `turns_per_launch` turns runs for this handle's batch on this device, as text in
  * buf (for benchmark records and logs): the kernel mapping (two / four lanes per env), the env range and wavefront count of

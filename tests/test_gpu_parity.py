@@ -351,6 +351,47 @@ def test_turn_can_be_captured_in_a_hip_graph(evg, oracle_mod):
     env.close()
 
 
+@pytest.mark.parametrize("shape", ["four_lane", "two_lane", "chunked"])
+def test_persistent_rollout_can_be_captured_in_a_hip_graph(evg, oracle_mod, shape):
+    """The PERSISTENT form inside a caller's graph: a rollout launch (launch plan) only enqueues -- a chunked launch zeroes its queues and
+    progress flags with a memset on the stream and keeps nothing on the host -- so torch.cuda.graph can capture it (the library then
+    enqueues plainly instead of replaying its own cached graph) and every replay plays the next turns: 4 replays of a 40-turn launch
+    after an uncaptured one == 200 oracle turns, for the four-lane kernel, the plain two-lane kernel and the chunked plan (2 chunks).
+    Outside a capture the library replays its OWN cached hipGraph of the plan (every other persistent test runs that path)."""
+    import torch
+    cap2 = 32 * 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    N = {"four_lane": 3000, "two_lane": cap2 - 32 * 5 - 7, "chunked": cap2 + 2048}[shape]
+    seed, tpl = 55, 40
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    plan = env.launch_plan(tpl)[1]
+    assert {"four_lane": "four lanes", "two_lane": "two lanes per env, persistent>", "chunked": "chunked"}[shape] in plan, plan
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset(); ora.reset()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env.rollout_random(tpl, turns_per_launch=tpl)            # warm-up on a side stream (also fills the library's own graph cache)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        env.rollout_random(tpl, turns_per_launch=tpl)            # captured, not executed
+    for _ in range(4):
+        g.replay()
+    torch.cuda.synchronize()
+    for t in range(5 * tpl - 1):
+        ora.step_noobs(ora.random_actions())
+    a = ora.random_actions()
+    o_obs, _, _, _ = ora.step(a)
+    assert np.array_equal(_np(env._actions), a)
+    _compare_whole_batch(env, ora, o_obs, ("persistent launch replayed from a caller's graph", shape))
+    env.rollout_random(tpl, turns_per_launch=tpl)                # and the library's own graph of the same launch still works afterwards
+    for t in range(tpl):
+        o_obs, _, _, _ = ora.step(ora.random_actions())
+    _compare_whole_batch(env, ora, o_obs, ("library graph after the caller's", shape))
+    assert env.check_fault() == 0
+    env.close()
+
+
 @pytest.mark.parametrize("seats", [("cycle_rush_turn25", "swarm"), ("cycle_target_node11P2", "dfs_attack"), ("random_actions_delay", "base_rush_v1"),
                                    ("swarm", "cycle_target_node1"), ("bull_rush", "all_cycle")])
 def test_native_policy_rollout_forms_agree(evg, seats):
@@ -1472,9 +1513,11 @@ def test_a_lost_chunk_hand_over_ends_the_launch_and_is_reported(evg):
         env.episode_stats_device()
     with pytest.raises(evg.EvgFault):
         env.get_state()
-    rows = env.packed_episode_results()
+    counts = torch.zeros(4, dtype=torch.int64, device=env.device)
+    rows = env.packed_episode_results(counts=counts)
     w = _np(rows)
     assert (w[:, 2] == -2).all() and np.isnan(w[:, :2]).all() and (w[:, 3] == -1).all()        # poisoned: winner -2 is no EVG_WINNER_* value
+    assert _np(counts).tolist() == [-1, -1, -1, -1]
     with pytest.raises(evg.EvgFault, match="poisoned"):
         evg.ResultGather.win_counts(rows)
     with pytest.raises(evg.EvgFault, match="poisoned"):
@@ -1488,7 +1531,9 @@ def test_a_lost_chunk_hand_over_ends_the_launch_and_is_reported(evg):
     out = ok.rollout_random(150, turns_per_launch=150, time_kernel=True)
     assert out[-1] > 0 and ok.check_fault() == 0
     assert ok.episode_stats()["totals"][0] >= N
-    assert (_np(ok.packed_episode_results())[:, 2] >= 0).all()
+    counts = torch.zeros(4, dtype=torch.int64, device=ok.device)
+    w = _np(ok.packed_episode_results(counts=counts))[:, 2]
+    assert (w >= 0).all() and _np(counts).tolist() == [int((w == k).sum()) for k in (0, 1, 2)] + [0]      # the pack kernel's own win bookkeeping of its rows
     ok.close()
 
 
@@ -1697,6 +1742,22 @@ def test_step_vs_policy_equals_two_launch_path_without_auto_reset(evg):
         for k in ("groups", "nodes", "health", "env"):
             assert np.array_equal(sa[k], sb[k]), k
         assert bool(a_env.done.any())                            # games did end (time expired at the latest): frozen envs were stepped
+    # the native driver of the same loop (evg_rollout_vs_policy: per turn evg_random_actions_seat into a tensor, then evg_step_vs_policy)
+    a_env.reset(); b_env.reset()
+    a_env.scripted_reset(); b_env.scripted_reset()
+    out = a_env.rollout_vs(60, "swarm", seat=1, time_kernel=True)
+    assert out[-1] > 0
+    for t in range(60):
+        ob, _, db, ib = b_env.step_vs("swarm", b_env.random_actions_seat(1), seat=1)
+    assert torch.equal(out[0], ob) and torch.equal(a_env.scores, b_env.scores) and torch.equal(a_env._actions_seat, b_env._actions_seat)
+    sa, sb = a_env.get_state(), b_env.get_state()
+    assert all(np.array_equal(sa[k], sb[k]) for k in sa)
+    unfinished = evg.EvergladesVecEnv(100, seed=2)                 # rows of envs that have not finished an episode count as such
+    unfinished.reset()
+    cnt = torch.zeros(4, dtype=torch.int64, device=unfinished.device)
+    unfinished.packed_episode_results(counts=cnt)
+    assert _np(cnt).tolist() == [0, 0, 0, 100]
+    unfinished.close()
     with pytest.raises(ValueError):
         a_env.step_vs("swarm", torch.zeros((N, 7), dtype=torch.int32, device=a_env.device))
     with pytest.raises(evg.EvgError):

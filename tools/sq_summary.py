@@ -21,7 +21,9 @@ for form, (tail, tpl, nwin) in FORMS.items():
     mean, meta = {}, None
     for d in sorted(x for x in glob.glob(os.path.join(P, form + "_p*")) if os.path.isdir(x)):
         rows, m = counter_rows(d, form)
-        rows = timed_window(rows, form)
+        keep = [i for i, x in enumerate(m) if not any(k in x["name"] for k in _prof.ACTION_KERNELS)]      # the step kernel only (two-kernel forms list the action kernel too)
+        rows, m = [rows[i] for i in keep], [m[i] for i in keep]
+        rows = rows[-FORMS[form][2]:]
         meta = m[-1]
         for c in rows[0]:
             mean[c] = sum(r[c] for r in rows) / len(rows)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (libevg_diag.so): single-turn launches of the step kernel with the wave in hardware slot 1 of every SIMD delayed
-by N x 64 cycles at its start.  Prints the mean step-kernel time per launch in a desynchronised steady state."""
+by N x 64 cycles at its start.  Prints the STREAM time per launch (two events around 160 back-to-back launches: kernel + launch gap; the kernel alone is in the rocprofv3 traces
+under profiles/) in a desynchronised steady state."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,5 +20,5 @@ for a, b, h in [(a_, 0, 0) for a_ in SWEEP]:   # delay = slot x (a - 1) + simd x
     torch.cuda.synchronize()
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record(); env.rollout_random(300); t1.record(); torch.cuda.synchronize()
-    print("stagger slot x (%2d - 1) + simd x %2d (x 64 cycles): step kernel %s us per launch; 300 launches back to back: %.2f us per turn" % (a, b, ["%.2f" % r for r in res], t0.elapsed_time(t1) / 300 * 1e3), flush=True)
+    print("stagger slot x (%2d - 1) + simd x %2d (x 64 cycles): stream time %s us per launch (160 launches each); 300 launches back to back: %.2f us per turn" % (a, b, ["%.2f" % r for r in res], t0.elapsed_time(t1) / 300 * 1e3), flush=True)
     env.close()
