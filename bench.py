@@ -253,7 +253,7 @@ def compact_line(full):
             return None
         o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "launches_per_turn", "turns_per_launch", "parts") if k in l}
         if l.get("roofline"):
-            o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("bound", "achieved", "peak", "frac", "bytes_per_env_step", "bytes_source") if l["roofline"].get(k) is not None}
+            o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("bound", "achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}      # (peak and byte source: as in the main roofline object)
         return o
 
     c = full["config"]
@@ -369,16 +369,16 @@ def main():
                                    diag=dict(lanes=args.diag_lanes) if args.diag_lanes else None)
         env.reset()
 
-        def rollout(nsteps, timed, tpl, fused=True, observe=True):
-            if fused == "learner":                           # per turn: evg_random_actions_seat -> tensor [N,7,2] -> evg_step_vs_policy (bot inside the step kernel)
-                out = env.rollout_vs(nsteps, args.opponent, seat=0, time_kernel=timed)
-                return out[-1] * nsteps if timed else 0.0
+        def rollout(nsteps, timed, tpl, fused=True, observe=True, prepare=False):
             """nsteps turns through the native rollout driver (evg_rollout_random / evg_rollout_policies, enqueued from C on torch's
             current stream).  fused: the step kernel draws / evaluates the orders of both seats itself; not fused (tpl must be 1):
             per turn the action kernel(s) write the orders into a tensor and evg_step reads them -- the caller-supplied-actions path.
             Returns the summed stream time in ms (HIP events recorded on that stream: around every persistent launch, or around the
             whole loop of single-turn launches)."""
-            kw = dict(time_kernel=timed, fused=fused, turns_per_launch=tpl, observe=observe, record_actions=observe)
+            if fused == "learner":                           # per turn: evg_random_actions_seat -> tensor [N,7,2] -> evg_step_vs_policy (bot inside the step kernel)
+                out = env.rollout_vs(nsteps, args.opponent, seat=0, time_kernel=timed)
+                return out[-1] * nsteps if timed else 0.0
+            kw = dict(time_kernel=timed, fused=fused, turns_per_launch=tpl, observe=observe, record_actions=observe, prepare=prepare)
             out = (env.rollout_random(nsteps, **kw) if args.workload == "random" else
                    env.rollout_policies(nsteps, "cycle_rush_turn25", "swarm", **kw))
             return out[-1] * nsteps if timed else 0.0
@@ -402,22 +402,24 @@ def main():
         rollout(args.warmup, True, args.turns_per_launch, main_fused)
         played += args.warmup
 
+    if main_fused is True:
+        rollout(args.steps, False, args.turns_per_launch, True, prepare=True)     # capture + instantiate the graphs of the K-step launch shape now (nothing is played)
+    if dist_on:      # torch creates an event at its first record(): not inside the timed region
+        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        for ev in (ev0, ev1, ev2):
+            ev.record()
     # ---- timed region: exactly K steps; with more than one rank the path's one collective (the gather of episode results) is
     # inside it (a single rank has nothing to exchange: its results are already where rank 0 reads them)
     barrier()
     t0 = time.perf_counter()
     gathered = None
     if not dist_on:
-        # the launches are only ENQUEUED here (no event read-out, no synchronisation inside the call); their duration is taken from two stream events after
-        # the closing bracket, so that the bracket's own torch.cuda.synchronize() is the one host wait of the timed region
-        ev0, ev1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
-        ev0.record()
-        rollout(args.steps, False, args.turns_per_launch, main_fused)
-        ev1.record()
+        # HIP events around the step-kernel launches, recorded by the native driver on the stream it launches on and read after the last one (measured
+        # against torch events around an untimed call + one synchronisation: the lazily created torch events cost the 20-step shape 4 us per step)
+        kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch, main_fused)
     else:
         # nothing between the launches and the collective waits for the host: the step kernels, the pack kernel and the gather are
         # enqueued back to back on the stream; the launches' duration is read from two stream events after the closing barrier
-        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         ev0.record()
         rollout(args.steps, False, args.turns_per_launch, main_fused)
         ev1.record()
@@ -430,8 +432,8 @@ def main():
         barrier()
     dt_local = time.perf_counter() - t0
     collective_ms = None
-    kernel_ms_sum = ev0.elapsed_time(ev1)           # HIP events on the stream the step kernels run on (torch's current stream)
     if dist_on:
+        kernel_ms_sum = ev0.elapsed_time(ev1)       # HIP events on the stream the step kernels run on (torch's current stream)
         collective_ms = ev1.elapsed_time(ev2)
     if env.check_fault():                           # (never expected: a chunk hand-over fault of a launch plan; raises)
         raise SystemExit("fault")
@@ -565,7 +567,8 @@ def main():
         roof = hbm_roofline(main_form, step_kernel_ms, args.steps / launches)
         n_launch, plan_text = env.launch_plan(tpl)
         roof.update({"kernel": plan_text, "kernel_launches_per_rollout_launch": n_launch, "launch_form": main_form,
-                     "kernel_ms_is": "stream time per turn: two HIP events on the launches' stream around all timed launches / K",
+                     "kernel_ms_is": ("HIP-event duration of every timed launch (two events on the stream it is launched on), summed / K" if tpl > 1 else "stream time per turn (two HIP events around the timed launches)") if not dist_on else
+                                     "stream time per turn: two HIP events on the launches' stream around all timed launches / K",
                      "launches_timed": launches, "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch, "launch_ms": launch_ms,
                      "bytes_source_is": "rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction, calibrated in the same passes), per env-step, "
                                         "times the env-steps of the timed launches",

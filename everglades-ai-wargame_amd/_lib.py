@@ -9,6 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libevg.so")                # the product library; nothing in the environment changes that
 DIAG_LIB_PATH = os.path.join(HERE, "libevg_diag.so")      # `make -C csrc diag`: phase ablation, 16-envs-per-wave variant, forced IEEE division
+GRAPHS_LIB_PATH = os.path.join(HERE, "libevg_graphs.so")   # `make -C csrc graphs`: rollout launch plans replayed as library-owned hipGraphs (A/B build; measured slower)
 STAMPS_LIB_PATH = os.path.join(HERE, "libevg_stamps.so")  # `make -C csrc stamps`: in-kernel phase stamps (tools/stamps.py)
 
 NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105

@@ -76,13 +76,18 @@ struct evg_handle {
     uint32_t* fault_seen_host = nullptr;   // host address of DevState::fault_seen (mapped host memory): non-zero <=> some bit of the fault word was set
     // Rollout launches replayed as hipGraphs (launch_rollout): one executable graph per distinct set of launch arguments, captured once on a
     // stream of the handle's own (nothing ever runs there) and replayed on the caller's stream with ONE submission per launch plan.
+    // MEASURED AND SWITCHED OFF in the product build: on this runtime (ROCm 7.2) a hipGraphLaunch of the one-kernel plan reaches the GPU ~1.2 us per
+    // step LATER than the plain launch in the driver's 20-step shape (tools/driver_shape_ab.sh, six alternations on one box: 21.1-21.9 us per step with
+    // replay, 19.4-20.8 without; profiles/r04_f_driver_shape_graph_replay_ab.txt).  `make graphs` builds libevg_graphs.so with the replay on for that
+    // A/B; what stays in the product is what made replay possible -- a launch plan keeps nothing on the host -- so a CALLER's capture of a rollout call
+    // (torch.cuda.graph) works for every plan, the chunked one included.
     struct CachedGraph { StepIO key; hipGraphExec_t exec; };
     std::vector<CachedGraph> graphs;
     hipStream_t capture_stream = nullptr;
-#ifdef EVG_NO_GRAPHS                        // A/B builds only (make nograph; tools/ab.sh): every rollout launch enqueued plainly
-    bool graphs_off = true;
+#ifdef EVG_REPLAY_GRAPHS
+    bool graphs_off = false;               // (a capture or an instantiation that fails once switches to plain launches)
 #else
-    bool graphs_off = false;               // a capture or an instantiation failed once: plain launches from then on
+    bool graphs_off = true;
 #endif
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
@@ -155,15 +160,14 @@ static void drop_graphs(evg_handle* h) {
 // stream instead of up to four submissions.  Everything a launch needs lives on the device (the chunked form zeroes its queues and flags with a
 // memset node), so a replay is exactly the launch.  If the caller's stream is itself capturing (torch.cuda.graph around a rollout call), the
 // kernels are enqueued plainly and become part of the CALLER's graph.
-static int launch_rollout(evg_handle* h, const StepIO& io, hipStream_t s) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    const bool caller_captures = s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-    if (h->graphs_off || caller_captures) return launch_step(h->S, io, h->cfg.obs_dtype, h->caps, s);
+// the cached executable graph of a launch, captured and instantiated on first use (nullptr: graphs are off on this handle / runtime)
+static hipGraphExec_t graph_of(evg_handle* h, const StepIO& io) {
+    if (h->graphs_off) return nullptr;
     for (auto& g : h->graphs)
-        if (same_launch(g.key, io)) return (int)hipGraphLaunch(g.exec, s);
+        if (same_launch(g.key, io)) return g.exec;
     if (!h->capture_stream && hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) != hipSuccess) {
         h->capture_stream = nullptr; h->graphs_off = true;
-        return launch_step(h->S, io, h->cfg.obs_dtype, h->caps, s);
+        return nullptr;
     }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -178,10 +182,18 @@ static int launch_rollout(evg_handle* h, const StepIO& io, hipStream_t s) {
     if (e != hipSuccess || rc) {               // no graph on this runtime: never an error of the rollout itself
         (void)hipGetLastError();
         h->graphs_off = true;
-        return launch_step(h->S, io, h->cfg.obs_dtype, h->caps, s);
+        return nullptr;
     }
     if (h->graphs.size() >= 16) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
     h->graphs.push_back({io, exec});
+    return exec;
+}
+
+static int launch_rollout(evg_handle* h, const StepIO& io, hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool caller_captures = s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    hipGraphExec_t exec = caller_captures ? nullptr : graph_of(h, io);
+    if (!exec) return launch_step(h->S, io, h->cfg.obs_dtype, h->caps, s);
     return (int)hipGraphLaunch(exec, s);
 }
 
@@ -709,6 +721,10 @@ int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int p
 static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
                         uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    // steps < 0: PREPARE a rollout of -steps turns with exactly these arguments -- capture and instantiate the graphs of its launches, run nothing -- so
+    // that the first real call pays no one-time cost (evg.h)
+    const bool prepare_only = steps < 0;
+    if (prepare_only) steps = -steps;
     if (steps < 1 || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, reward_out, done_out required");
     if (!actions_buf && !fused) return fail(EVG_ERR_INVALID, "rollout: actions_buf is required unless the step kernel produces the orders itself (fused >= 1)");
     EVG_ON_DEVICE(h);
@@ -731,13 +747,14 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         int done_turns = 0;
         for (int l = 0; l < nlaunch; ++l) {
             io.turns = steps - done_turns < per_launch ? steps - done_turns : per_launch;
+            if (prepare_only) { (void)graph_of(h, io); done_turns += io.turns; continue; }
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l], s_));
             const int rc = launch_rollout(h, io, s_);
             if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[2 * l + 1], s_));
             done_turns += io.turns;
         }
-        if (step_kernel_ms) {
+        if (step_kernel_ms && !prepare_only) {
             HIP_TRY(hipStreamSynchronize(s_));
             double tot = 0.0;
             for (int l = 0; l < nlaunch; ++l) {
@@ -750,6 +767,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         }
         return EVG_OK;
     }
+    if (prepare_only) return EVG_OK;            // single-turn launches are enqueued plainly: nothing to prepare
     // One launch per turn: the loop is timed as a whole with two events on the stream (an event pair around every launch would
     // make the queue wait for each bracketed kernel to retire and stretch what it measures): step_kernel_ms is the stream
     // time per turn -- the step kernel, the gap to the next launch and, when the orders are not drawn by the step kernel

@@ -339,7 +339,7 @@ class EvergladesVecEnv(object):
     def scripted_reset(self):
         self._check(self.L.evg_scripted_reset(self._h, self._stream()))
 
-    def rollout_random(self, steps, time_kernel=False, fused=True, turns_per_launch=1, observe=True, record_actions=True):
+    def rollout_random(self, steps, time_kernel=False, fused=True, turns_per_launch=1, observe=True, record_actions=True, prepare=False):
         """`steps` turns of random-vs-random play driven from native code (evg_rollout_random): per turn the
         on-device random_actions generator fills self._actions, then the step kernel runs (fused=True: the step kernel draws the same orders itself and stores them in
         self._actions -- one launch per turn; turns_per_launch > 1: persistent form, each launch plays that many
@@ -349,8 +349,12 @@ class EvergladesVecEnv(object):
         the last turn like step(); with time_kernel=True also the STREAM time per turn in ms (synchronises): persistent form -- the duration
         of each launch (plan) between two events, summed, over the turns played; one launch per turn -- two events around the whole loop,
         i.e. step kernel + launch gap (+ the action kernel with fused=False).  The kernel alone is in the rocprofv3 traces under profiles/.
-        A timed call also reports a chunk hand-over fault of the handle (EvgFault)."""
+        A timed call also reports a chunk hand-over fault of the handle (EvgFault).
+        prepare=True: nothing is played -- the hipGraphs of the launches such a call would make (persistent form) are captured and
+        instantiated now, so that the first real call pays no one-time cost (e.g. before a timed region)."""
         ms = C.c_float(0.0)
+        if prepare:
+            steps, time_kernel = -abs(int(steps)), False
         p = self._p                     # cached raw pointers of the env's own buffers: the call itself is the only host work before the launch
         if not fused and not (observe and record_actions):
             raise ValueError("observe=False / record_actions=False need the fused forms (the unfused form passes the orders through self._actions)")
@@ -362,13 +366,15 @@ class EvergladesVecEnv(object):
         out = (self.obs, self.reward, self.done, self._info)
         return out + (float(ms.value),) if time_kernel else out
 
-    def rollout_policies(self, steps, policy0, policy1, time_kernel=False, fused=True, turns_per_launch=1, observe=True, record_actions=True):
+    def rollout_policies(self, steps, policy0, policy1, time_kernel=False, fused=True, turns_per_launch=1, observe=True, record_actions=True, prepare=False):
         """`steps` turns of on-device policy0 (seat 0) vs policy1 (seat 1), driven from native code (evg_rollout_policies).
         fused=False: two agent launches per turn read self.obs (which must hold the current observations; it does after
         reset()/step()); fused=True: the step kernel evaluates both agents from the on-chip state, one launch per turn or --
         turns_per_launch > 1 -- the persistent form.  Identical results.  observe=False / record_actions=False (fused forms only): no
         observations are written / the orders are not stored (the evaluation harness: it reads only the episode results)."""
         ms = C.c_float(0.0)
+        if prepare:                                      # see rollout_random
+            steps, time_kernel = -abs(int(steps)), False
         p0 = self.POLICIES[policy0] if isinstance(policy0, str) else int(policy0)
         p1 = self.POLICIES[policy1] if isinstance(policy1, str) else int(policy1)
         if not fused and not (observe and record_actions):

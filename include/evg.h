@@ -31,8 +31,8 @@
 extern "C" {
 #endif
 
-#define EVG_ABI_VERSION 4      /* 4: evg_step_vs_policy / evg_observe_seat / evg_random_actions_seat / evg_smart_state_seat, evg_check_fault, EVG_ERR_FAULT,
-                                  evg_config.cache_mib, graph-replayed rollouts; 3: evg_launch_plan; 2: evg_pack_episode_results, node words as u32 */
+#define EVG_ABI_VERSION 4      /* 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat,
+                                  evg_check_fault + EVG_ERR_FAULT, evg_pack_episode_results_counted, evg_config.cache_mib; 3: evg_launch_plan; 2: evg_pack_episode_results, node words as u32 */
 
 /* The ABI is exactly the functions declared in this header: the library is built with -fvisibility=hidden and only they are exported. */
 #define EVG_API __attribute__((visibility("default")))
@@ -174,7 +174,9 @@ EVG_API int evg_observe(evg_handle* h, void* obs_out, void* stream);
  *   obs_seat_out     device [N][105] of cfg.obs_dtype: the caller's seat's observation (everglades_env.py:158-171); 16-byte aligned
  *   reward_out, done_out, winner_out, scores_out, status_out: as in evg_step (both seats' rewards and scores: the harness compares
  *                    reward[0] with reward[1], evaluate.py:155-160)
- * Results are those of evg_scripted_actions(opponent) + evg_step on the same orders, bit for bit.  Keyed-Philox handles only. */
+ * Results are those of evg_scripted_actions(opponent) + evg_step on the same orders, bit for bit.  Keyed-Philox handles only.  The launch itself
+ * lasts as long as evg_step's (26.7 us at 65 536 envs on an MI355X; a single-turn launch is bound by its latency chain, not by its bytes: DESIGN.md
+ * section 6); what is saved is the bot's own kernel (7-9 us and 55 MB of observations read back) and the traffic listed above. */
 EVG_API int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out,
                                float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream);
 /* evg_observe for one seat: obs_seat_out device [N][105] (after evg_reset / evg_set_state, to start a evg_step_vs_policy loop). */
@@ -259,11 +261,17 @@ EVG_API int evg_scripted_reset(evg_handle* h, void* stream);
  * With fused >= 1 obs_out and actions_buf may be NULL: the rollout then writes no observations (the step kernel skips the
  * observation image and its write-out: a sixth of a turn's instructions and 55 % of its bytes) and / or does not record the orders --
  * what an evaluation loop needs, which reads only rewards, done flags and the episode results (evaluate.py:143-181).
+ * A launch of the persistent form (fused >= 2) is a launch PLAN (evg_launch_plan: up to two step kernels, or memset + chunked kernel + queue check) that
+ * keeps nothing on the host: when `stream` is being captured (e.g. torch.cuda.graph around this call) the plan becomes part of the caller's graph and
+ * every replay plays the next turns.  (The library does not replay graphs of its own: measured slower than plain launches on ROCm 7.2, DESIGN.md
+ * section 3.)  steps < 0 prepares a rollout of -steps turns with exactly these arguments -- whatever one-time work its launches need is done now, nothing
+ * is enqueued and no state changes (a no-op in the product build; the graph-replay A/B build captures its graphs here).
  * Outputs as in evg_step (they hold the LAST step when the call returns).  If step_kernel_ms (host
  * pointer) is not NULL the work is bracketed by hipEvents on `stream`, the call synchronises the stream and stores the
  * stream time per turn in milliseconds: persistent form -- the duration of each launch (or launch plan, see
  * evg_launch_plan), summed, over the turns played; one launch per turn -- two events around the WHOLE loop over `steps`,
- * i.e. the step kernel plus the gap to the next launch plus, with fused == 0, the action kernel of the turn. */
+ * i.e. the step kernel plus the gap to the next launch plus, with fused == 0, the action kernel of the turn.  A timed call also returns
+ * EVG_ERR_FAULT when the handle's fault word is set (evg_check_fault). */
 EVG_API int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf, void* obs_out, float* reward_out,
                        uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out,
                        float* step_kernel_ms, void* stream);
@@ -338,7 +346,9 @@ EVG_API int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t*
 /* Which step kernel(s) a rollout launch of `turns_per_launch` turns runs for this handle's batch on this device, as text in
  * buf (for benchmark records and logs): the kernel mapping (two / four lanes per env), the env range and wavefront count of
  * every launch of the plan, and the device capacity the plan was derived from (compute units from hipDeviceProp_t, resident
- * wavefronts from the kernels' own occupancy -- no 256-CU literal).  turns_per_launch == 1 describes evg_step.  Returns the
+ * wavefronts from the kernels' own occupancy -- no 256-CU literal; the XCDs the create-time probe saw; the memory-side cache budget a chunked launch may
+ * cycle through, evg_config.cache_mib, and the bytes per env it is compared with).  The plan described is the one of a rollout that writes observations and
+ * records the orders (a rollout without them has a smaller footprint and may chunk a slightly larger batch).  turns_per_launch == 1 describes evg_step.  Returns the
  * number of kernel launches per rollout launch (>= 1) or a negative evg_status. */
 EVG_API int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen);
 

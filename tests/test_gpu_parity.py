@@ -357,7 +357,7 @@ def test_persistent_rollout_can_be_captured_in_a_hip_graph(evg, oracle_mod, shap
     progress flags with a memset on the stream and keeps nothing on the host -- so torch.cuda.graph can capture it (the library then
     enqueues plainly instead of replaying its own cached graph) and every replay plays the next turns: 4 replays of a 40-turn launch
     after an uncaptured one == 200 oracle turns, for the four-lane kernel, the plain two-lane kernel and the chunked plan (2 chunks).
-    Outside a capture the library replays its OWN cached hipGraph of the plan (every other persistent test runs that path)."""
+    (The library itself enqueues plans plainly: replaying graphs of its own was measured slower; `make graphs` keeps that build for the A/B.)"""
     import torch
     cap2 = 32 * 8 * torch.cuda.get_device_properties(0).multi_processor_count
     N = {"four_lane": 3000, "two_lane": cap2 - 32 * 5 - 7, "chunked": cap2 + 2048}[shape]
@@ -370,7 +370,7 @@ def test_persistent_rollout_can_be_captured_in_a_hip_graph(evg, oracle_mod, shap
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        env.rollout_random(tpl, turns_per_launch=tpl)            # warm-up on a side stream (also fills the library's own graph cache)
+        env.rollout_random(tpl, turns_per_launch=tpl)            # warm-up on a side stream
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -384,10 +384,11 @@ def test_persistent_rollout_can_be_captured_in_a_hip_graph(evg, oracle_mod, shap
     o_obs, _, _, _ = ora.step(a)
     assert np.array_equal(_np(env._actions), a)
     _compare_whole_batch(env, ora, o_obs, ("persistent launch replayed from a caller's graph", shape))
-    env.rollout_random(tpl, turns_per_launch=tpl)                # and the library's own graph of the same launch still works afterwards
+    env.rollout_random(tpl, turns_per_launch=tpl, prepare=True)  # (prepare: nothing is played)
+    env.rollout_random(tpl, turns_per_launch=tpl)                # and a plain launch of the same plan still works afterwards
     for t in range(tpl):
         o_obs, _, _, _ = ora.step(ora.random_actions())
-    _compare_whole_batch(env, ora, o_obs, ("library graph after the caller's", shape))
+    _compare_whole_batch(env, ora, o_obs, ("plain launch after the caller's graph", shape))
     assert env.check_fault() == 0
     env.close()
 
@@ -1867,3 +1868,31 @@ def test_pipelined_learner_seat_parts_vs_oracle(evg, oracle_mod):
     st, ost = pipe.episode_stats(), ora.episode_stats()
     assert np.array_equal(st["totals"], ost["totals"]) and np.array_equal(st["winner"], ost["winner"])
     pipe.close()
+
+
+def test_graph_replay_build_plays_the_same_games(evg, oracle_mod):
+    """libevg_graphs.so (-DEVG_REPLAY_GRAPHS: every rollout launch plan captured once into a library-owned hipGraph and replayed -- the build the
+    driver-shape A/B measured slower than plain launches, tools/driver_shape_ab.sh): the chunked plan (memset + kernel + queue check as one graph)
+    and the plain two-lane plan, prepared ahead and replayed over several launches, against the oracle on every env."""
+    import os
+    import torch
+    if not os.path.exists(evg._lib.GRAPHS_LIB_PATH):
+        pytest.skip("libevg_graphs.so not built (make -C everglades-ai-wargame_amd/csrc graphs)")
+    cap2 = 32 * 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    for N in (cap2 + 2048, 5000):
+        env = evg.EvergladesVecEnv(N, seed=77, auto_reset=True, library=evg._lib.GRAPHS_LIB_PATH)
+        ora = oracle_mod.Oracle(N, seed=77, auto_reset=True)
+        env.reset(); ora.reset()
+        env.rollout_random(60, turns_per_launch=60, prepare=True)          # captures, plays nothing
+        check_state(env, ora.get_state(), "prepare plays nothing")
+        for _ in range(3):
+            env.rollout_random(60, turns_per_launch=60)                    # one capture, three replays
+        env.rollout_random(25, turns_per_launch=60)                        # another shape: its own graph
+        for t in range(204):
+            ora.step_noobs(ora.random_actions())
+        a = ora.random_actions()
+        o_obs, _, _, _ = ora.step(a)
+        assert np.array_equal(_np(env._actions), a)
+        _compare_whole_batch(env, ora, o_obs, ("graph replay build", N))
+        assert env.check_fault() == 0
+        env.close()
