@@ -275,10 +275,15 @@ def compact_line(full):
         out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "valu_insts_per_wave_turn", "source")}
     if "distributed" in full:
         d = dict(full["distributed"])
-        d["collective"] = "pack kernel (rows + win counts) + gather to rank 0 + all_reduce of the win counts (= closing barrier)"
-        for k in ("collective_us_is", "closing_bracket"):
+        d["collective"] = "pack(rows+win counts) + gather to rank 0 + all_reduce(win counts) = closing barrier"
+        for k in ("collective_us_is", "closing_bracket", "rows_expected_per_rank"):
             d.pop(k, None)
-        d["per_rank"] = [{k: _r(v, 5) for k, v in r.items()} for r in d.get("per_rank") or []]
+        pr = d.get("per_rank") or []          # per rank, as columns (rank = position): an 8-rank line must still fit a driver's tail
+        d["per_rank"] = {k: [_r(r[k], 4) for r in pr] for k in ("seconds", "kernel_ms_per_step", "collective_us")}
+        if d.get("expected"):
+            d["expected"] = {k: _r(v, 5) for k, v in d["expected"].items() if k in ("value_if_wire_free", "per_gpu", "weak_scaling_efficiency_if_wire_free", "collective_us_1rank")}
+        for k in ("collective_us", "step_launches_us"):
+            d[k] = _r(d.get(k), 5)
         out["distributed"] = d
     if "cpu_baseline" in full:
         b = full["cpu_baseline"]

@@ -1,6 +1,7 @@
 /* c_client.c -- the drop-in boundary used from plain C: no Python, no torch, only include/evg.h and the HIP runtime for
  * the caller-owned device buffers.  Plays `turns` turns of N random-vs-random DemoMap games (the loop of the reference's
- * demo/random_demo.py:90-113, vectorised) and prints the win counters plus a checksum of the last observations.
+ * demo/random_demo.py:90-113, vectorised) and prints the win counters plus a checksum of the last observations; then the same number of turns of
+ * the learner-seat loop (evg_step_vs_policy: caller on seat 0, on-device swarm_agent on seat 1) with its own counters and checksum.
  *
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/c_client.c \
  *       -Leverglades-ai-wargame_amd -levg -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/everglades-ai-wargame_amd -Wl,-rpath,/opt/rocm/lib -o c_client
@@ -51,6 +52,29 @@ int main(int argc, char** argv) {
     printf("envs %d turns %d episodes %lld p0 %lld p1 %lld tie %lld obs_checksum %lld\n", n, turns, (long long)totals[0],
            (long long)totals[1], (long long)totals[2], (long long)totals[3], sum);
     free(host);
+
+    /* the turn the reference's scripts run (evaluate.py:85-93,143-152): a caller on seat 0 -- its 7 rows arrive in a tensor, here from the library's
+     * stand-in generator --, the on-device swarm_agent bot on seat 1 inside the step kernel, the caller's observation [N][105] only */
+    int32_t* seat_rows; float* seat_obs;
+    HIPCHECK(hipMalloc((void**)&seat_rows, (size_t)n * EVG_NUM_ACTIONS * 2 * sizeof(int32_t)));
+    HIPCHECK(hipMalloc((void**)&seat_obs, (size_t)n * EVG_OBS_LEN * sizeof(float)));
+    CHECK(evg_observe_seat(h, 0, seat_obs, NULL));
+    for (int t = 0; t < turns; ++t) {
+        CHECK(evg_random_actions_seat(h, 0, seat_rows, NULL));
+        CHECK(evg_step_vs_policy(h, 0, seat_rows, 0, EVG_POLICY_SWARM, seat_obs, reward, done, NULL, NULL, NULL, NULL));
+    }
+    uint32_t fault = 0;
+    CHECK(evg_check_fault(h, &fault));                      /* synchronises */
+    CHECK(evg_episode_stats(h, NULL, NULL, NULL, totals));
+    const size_t seat_elems = (size_t)n * EVG_OBS_LEN;
+    host = (float*)malloc(seat_elems * sizeof(float));
+    HIPCHECK(hipMemcpy(host, seat_obs, seat_elems * sizeof(float), hipMemcpyDeviceToHost));
+    sum = 0;
+    for (size_t i = 0; i < seat_elems; ++i) sum += (long long)host[i] * (long long)(1 + i % 7);
+    printf("vs_episodes %lld vs_p0 %lld vs_p1 %lld vs_tie %lld vs_obs_checksum %lld\n", (long long)totals[0], (long long)totals[1], (long long)totals[2],
+           (long long)totals[3], sum);
+    free(host);
+    hipFree(seat_rows); hipFree(seat_obs);
     hipFree(actions); hipFree(obs); hipFree(reward); hipFree(done);
     evg_destroy(h);
     return 0;

@@ -286,8 +286,8 @@ def test_bench_stdout_line_is_compact_and_complete():
     spec = importlib.util.spec_from_file_location("evg_bench2", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r03_q_bench_*.json")) if "compact" not in f)
-    assert len(files) >= 5
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r04_f_bench_*.json")) if "compact" not in f)
+    assert len(files) >= 7
     for f in files:
         full = json.loads(open(f).read())
         line = json.dumps(bench.compact_line(full), separators=(",", ":"))
@@ -302,6 +302,17 @@ def test_bench_stdout_line_is_compact_and_complete():
         if "cpu_baseline" in full:
             for k in ("value", "unit", "cores", "kind", "sample"):
                 assert k in c["cpu_baseline"]
-        for leg in ("one_launch_per_turn", "caller_actions_per_turn"):
+        for leg in ("one_launch_per_turn", "caller_actions_per_turn", "learner_vs_bot_per_turn"):
             if full["config"].get(leg):
                 assert c["config"][leg]["roofline"]["frac"] > 0 and c["config"][leg]["kernel_ms"] <= c["config"][leg]["ms_per_step"]
+        if full["config"].get("pipelined_halves_per_turn"):
+            leg = c["config"]["pipelined_halves_per_turn"]
+            assert leg["parts"] == 2 and leg["kernel_ms"] <= leg["ms_per_step"]
+        if "distributed" in full:
+            d = c["distributed"]
+            assert d["collective_us"] > 0 and d["gathered_wins_equal_sum_of_per_rank_counts"] is True and "expected" in d
+    # what a first multi-GPU line is read against: N x the committed one-rank RCCL rehearsal of the same shape, next to the one-GPU line of that shape
+    exp = bench.expected_if_wire_free(8, 20)
+    assert exp and "r04_f_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
+    assert 0.7 < exp["weak_scaling_efficiency_if_wire_free"] <= 1.0 and exp["collective_us_1rank"] > 0
+    assert bench.expected_if_wire_free(8, 12345) is None

@@ -728,6 +728,13 @@ def test_plain_c_client_of_the_abi(evg):
     chk = int((o * (1 + np.arange(o.size) % 7)).sum())
     assert (got["episodes"], got["p0"], got["p1"], got["tie"]) == tuple(int(x) for x in tot) and got["episodes"] >= 2 * N
     assert got["obs_checksum"] == chk
+    env.observe_seat(0)                                      # the client's second part: the learner-seat loop from plain C
+    for _ in range(turns):
+        so = env.step_vs("swarm", env.random_actions_seat(0), seat=0)[0]
+    tot = env.episode_stats()["totals"]
+    o = _np(so).astype(np.int64).reshape(-1)
+    assert (got["vs_episodes"], got["vs_p0"], got["vs_p1"], got["vs_tie"]) == tuple(int(x) for x in tot) and got["vs_episodes"] > got["episodes"]
+    assert got["vs_obs_checksum"] == int((o * (1 + np.arange(o.size) % 7)).sum())
     env.close()
 
 
@@ -834,6 +841,27 @@ def test_custom_tables_vs_oracle(evg, oracle_mod, force_ieee_div):
         o_obs, _, _, _ = ora.step(a)
     assert np.array_equal(_np(env.obs).astype(np.float64), o_obs) and np.array_equal(_np(env._actions), a)
     check_state(env, ora.get_state(), "persistent")
+    # bots evaluated from the ON-CHIP state (ChipView: board slots and own-numbering locations of player 1 go through this table set's NON-involutive
+    # p1_node_map and its inverse) against the oracle's agents, which read observations: the learner-seat turn on both seats, then the fused rollout
+    P = evg.EvergladesVecEnv.POLICIES
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for seat, pol in ((0, "cycle_target_node11P2"), (1, "cycle_rush_turn25"), (0, "cycle_target_node1")):
+        env.scripted_reset(); ora.scripted_reset()           # fresh agent objects for every bot
+        for tt in range(70):
+            rows = env.random_actions_seat(seat)
+            ora.scripted_actions(P[pol], 1 - seat, o_obs, oa)
+            oa[:, seat] = _np(rows)
+            so, _, _, info = env.step_vs(pol, rows, seat=seat)
+            o_obs, _, _, o_info = ora.step(oa)
+            assert np.array_equal(_np(so).astype(np.float64), o_obs[:, seat]) and np.array_equal(_np(info["scores"]), o_info["scores"]), ("step_vs, custom tables", pol, seat, tt)
+    env.scripted_reset(); ora.scripted_reset()
+    env.rollout_policies(90, "cycle_target_node11P2", "cycle_target_node", fused=True, turns_per_launch=30)
+    for tt in range(90):
+        ora.scripted_actions(P["cycle_target_node11P2"], 0, o_obs, oa)
+        ora.scripted_actions(P["cycle_target_node"], 1, o_obs, oa)
+        o_obs, _, _, _ = ora.step(oa)
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs) and np.array_equal(_np(env._actions), oa)
+    check_state(env, ora.get_state(), "fused bots, custom tables")
     env.close()
 
 
