@@ -252,6 +252,8 @@ def compact_line(full):
         if not l:
             return None
         o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "launches_per_turn", "turns_per_launch", "parts") if k in l}
+        if l.get("learner_vs_bot"):
+            o["learner_vs_bot"] = {k: _r(l["learner_vs_bot"][k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms")}
         if l.get("roofline"):
             o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("bound", "achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}      # (peak and byte source: as in the main roofline object)
         return o
@@ -523,6 +525,15 @@ def main():
                         "kernel_ms_is": "stream time per turn of the slowest part (two HIP events around its 600 single-turn launches); ms_per_step is the wall clock per turn of the WHOLE batch",
                         "stream_ms_per_turn_of_every_part": kp, "launches_per_turn": args.pipeline,
                         "what": "PipelinedVecEnv.rollout_random_free: every part plays one launch per turn (orders drawn in the step kernel) on its own stream, nothing joins them"}
+            # ... and the learner-seat turn on the same two parts: per part and turn the learner's stand-in kernel + evg_step_vs_policy (bot inside), free-running
+            pipe.rollout_vs_free(16, args.opponent, seat=0, time_kernel=True)
+            barrier()
+            t1 = time.perf_counter()
+            kl = pipe.rollout_vs_free(600, args.opponent, seat=0, time_kernel=True)
+            barrier()
+            dl = time.perf_counter() - t1
+            pipe_leg["learner_vs_bot"] = {"env_steps_per_s": total * 600 / dl, "ms_per_step": dl / 600 * 1e3, "kernel_ms": max(kl), "launches_per_turn": 2 * args.pipeline,
+                                          "what": "PipelinedVecEnv.rollout_vs_free: per part and turn evg_random_actions_seat + evg_step_vs_policy(opponent `%s` inside the step kernel)" % args.opponent}
             pipe.close()
         if args.obs_dtype != "float64":
             env64, rollout64 = make_env("float64")

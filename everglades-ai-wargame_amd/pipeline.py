@@ -162,11 +162,19 @@ class PipelinedVecEnv(object):
         seat=0|1, that seat's rows [n_i, 7, 2]."""
         return self.parts[i].random_actions() if seat is None else self.parts[i].random_actions_seat(seat)
 
+    def rollout_vs_free(self, steps, policy, seat=0, time_kernel=False):
+        """The same free-running benchmark for the learner-seat turn: every part plays `steps` turns of EvergladesVecEnv.rollout_vs (per turn the
+        caller seat's stand-in orders into a tensor, then step_vs with the on-device bot `policy`) on its own stream."""
+        return self._free(lambda part: part.rollout_vs(steps, policy, seat=seat, time_kernel=time_kernel), time_kernel)
+
     def rollout_random_free(self, steps, time_kernel=False):
         """Benchmark of the overlap: every part plays `steps` turns of random vs random, one launch per turn (orders drawn in the step
         kernel), FREE-RUNNING on its own stream -- what the double-buffered pattern converges to when the policy is cheap.  The native
         loops are started from one host thread per part (they only enqueue).  Returns the per-part stream time per turn in ms
         (time_kernel=True; synchronises) or None."""
+        return self._free(lambda part: part.rollout_random(steps, time_kernel=time_kernel, fused=True, turns_per_launch=1), time_kernel)
+
+    def _free(self, play, time_kernel):
         torch = self._torch()
         cur = torch.cuda.current_stream(self.device)
         for i in range(self.pipeline):
@@ -178,7 +186,7 @@ class PipelinedVecEnv(object):
         def run(i):
             try:
                 with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
-                    out = self.parts[i].rollout_random(steps, time_kernel=time_kernel, fused=True, turns_per_launch=1)
+                    out = play(self.parts[i])
                     ms[i] = out[-1] if time_kernel else None
                     self._stepped[i].record(self.streams[i])
             except Exception as ex:          # re-raised on the calling thread

@@ -1893,6 +1893,14 @@ def test_pipelined_learner_seat_parts_vs_oracle(evg, oracle_mod):
     torch.cuda.synchronize()
     assert np.array_equal(_np(pipe.obs_seat).astype(np.float64), o_obs[:, seat]) and np.array_equal(_np(pipe.scores), o_info["scores"])
     check_state(pipe, ora.get_state(), "pipelined learner seat")
+    ms = pipe.rollout_vs_free(30, pol, seat=seat, time_kernel=True)        # the free-running benchmark form continues the same games
+    assert len(ms) == 3 and all(m > 0 for m in ms)
+    for t in range(30):
+        ora.scripted_actions(pid, 1 - seat, o_obs, oa)
+        oa[:, seat] = ora.random_actions()[:, seat]
+        o_obs, _, _, o_info = ora.step(oa)
+    assert np.array_equal(_np(pipe.obs_seat).astype(np.float64), o_obs[:, seat]) and np.array_equal(_np(pipe._actions_seat), oa[:, seat])
+    check_state(pipe, ora.get_state(), "pipelined learner seat, free-running")
     st, ost = pipe.episode_stats(), ora.episode_stats()
     assert np.array_equal(st["totals"], ost["totals"]) and np.array_equal(st["winner"], ost["winner"])
     pipe.close()
