@@ -671,6 +671,7 @@ int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream) {
 
 int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream) {
     if (!h || !obs || !features_out || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
+    if ((reinterpret_cast<uintptr_t>(features_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "features_out must be 16-byte aligned");
     EVG_ON_DEVICE(h);
     const int rc = launch_smart_state(h->S, player, obs, 0, features_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -679,6 +680,7 @@ int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_
 
 int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_out, void* stream) {
     if (!h || !obs_seat || !features_out) return fail(EVG_ERR_INVALID, "bad argument");
+    if ((reinterpret_cast<uintptr_t>(features_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "features_out must be 16-byte aligned");
     EVG_ON_DEVICE(h);
     const int rc = launch_smart_state(h->S, 0, obs_seat, 1, features_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));

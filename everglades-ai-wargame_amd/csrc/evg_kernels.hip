@@ -1642,18 +1642,24 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
     // env goes into a small per-wave table -- the 34 features all swarms share and the 12 per-swarm health features are
     // one IEEE f64 division each (46 lanes: one division sequence per env instead of one per output element), then the
     // 12 in-transit flags, the constants 0 and 1 and the 12 x 11 one-hot node entries -- and the env's 12 x 59 floats
-    // are streamed out as table[idx] in 64-float (256-byte) coalesced stores; idx depends only on the position in the
-    // row and is computed once per lane.  HBM-bound by the 2 832 B written per env.
-    constexpr int F = 59, WPB = 4, NIT = (NG * F + 63) / 64;
+    // are streamed out as table[idx] in 16-byte-per-lane (1 KiB per wavefront) coalesced stores; idx depends only on the position in
+    // the row and is computed once per lane.  HBM-bound by the 2 832 B written per env.  Every wavefront works on its own env with its own
+    // LDS rows, so the phases are separated by wavefront-scope fences, not block barriers: a barrier would also wait (vmcnt(0)) for the
+    // stores of the pass to be acknowledged before the next env's row is even requested.
+    constexpr int F = 59, WPB = 4, NV = NG * F / 4, NIT = (NV + 63) / 64;          // 177 float4 per env: three per lane
+    static_assert(NG * F % 4 == 0, "an env's features are a whole number of float4");
     constexpr int T_HP = 34, T_MOV = 46, T_ZERO = 58, T_ONE = 59, T_HOT = 64, T_SIZE = T_HOT + NG * NN;
     __shared__ int   row[WPB][128];
     __shared__ float tab[WPB][T_SIZE + 4];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint8_t idx[NIT];
+    uint8_t idx[NIT][4];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-        const int j = lane + 64 * i, sw = j / F, f = j - sw * F;
-        idx[i] = (uint8_t)(f < 34 ? f : (f < 45 ? T_HOT + sw * NN + (f - 34) : (f == 45 ? T_HP + sw : (f == 46 ? T_MOV + sw : (f - 47 == sw ? T_ONE : T_ZERO)))));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = 4 * (lane + 64 * i) + c, sw = j / F, f = j - sw * F;
+            idx[i][c] = (uint8_t)(f < 34 ? f : (f < 45 ? T_HOT + sw * NN + (f - 34) : (f == 45 ? T_HP + sw : (f == 46 ? T_MOV + sw : (f - 47 == sw ? T_ONE : T_ZERO)))));
+        }
     }
     if (lane == 0) { tab[w][T_ZERO] = 0.f; tab[w][T_ONE] = 1.f; }
     const int passes = (N + (int)gridDim.x * WPB - 1) / ((int)gridDim.x * WPB);
@@ -1663,7 +1669,7 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
         const OT* o = obs + (seat_only ? (size_t)(live ? e : 0) : (size_t)(live ? e : 0) * 2 + player) * OBS;     // seat_only: obs is [N][105]
         row[w][lane] = live ? (int)o[lane] : 0;                              // every observation value is an integer
         row[w][lane + 64] = (live && lane + 64 < OBS) ? (int)o[lane + 64] : 0;
-        __syncthreads();
+        WAVE_SYNC();
         const int* r = row[w];
         double num = 0.0, den = 1.0;
         if (lane == 0) { num = (double)r[0]; den = 150.0; }                                          // :280
@@ -1685,14 +1691,15 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
             const int sw = t / NN, n = t - sw * NN;
             tab[w][T_HOT + t] = (r[45 + 5 * sw] == n + 1) ? 1.f : 0.f;
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (live) {
-            float* dst = out + (size_t)e * NG * F;
+            float4* dst = reinterpret_cast<float4*>(out + (size_t)e * NG * F);                        // 2 832 B per env: 16-byte aligned rows
 #pragma unroll
             for (int i = 0; i < NIT; ++i)
-                if (lane + 64 * i < NG * F) dst[lane + 64 * i] = tab[w][idx[i]];                      // one-hot swarm id (:298) = the two constants
+                if (lane + 64 * i < NV)                                                               // one-hot swarm id (:298) = the two constants
+                    dst[lane + 64 * i] = make_float4(tab[w][idx[i][0]], tab[w][idx[i][1]], tab[w][idx[i][2]], tab[w][idx[i][3]]);
         }
-        __syncthreads();
+        WAVE_SYNC();
     }
 }
 

@@ -201,7 +201,7 @@ EVG_API int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream);
 
 /* Consumer-side preprocessing of the reference's strongest agent family (agents/Smart_State/DQNAgent.py:200-300,
  * create_swarm_obs): from `player`'s rows of obs (device [N][2][105] of cfg.obs_dtype) to features_out, device float
- * [N][12][59]: per swarm {turn/150, 11 x control/100, 11 x enemy units/100, 11 x idle allied groups/12, one-hot node,
+ * [N][12][59] (16-byte aligned): per swarm {turn/150, 11 x control/100, 11 x enemy units/100, 11 x idle allied groups/12, one-hot node,
  * avg health x alive / 1000, in transit, one-hot swarm id}; each value is the reference's float64 expression rounded to
  * float32.  evg_move_table fills table[11][5] with Move_Translation.get_move(node0, direction) (host memory). */
 EVG_API int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream);

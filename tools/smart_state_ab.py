@@ -1,0 +1,19 @@
+import sys, torch
+sys.path.insert(0, '.')
+import everglades_amd as evg
+for lib in ("libevg_base.so", "libevg.so"):
+    env = evg.EvergladesVecEnv(65536, seed=3, auto_reset=True, library="everglades-ai-wargame_amd/" + lib)
+    env.reset(); env.rollout_random(60, turns_per_launch=60)
+    so = env.observe_seat(0)
+    for name, fn in (("full obs", lambda: env.smart_state(0)), ("seat obs", lambda: env.smart_state(0, so))):
+        out = torch.empty((65536, 12, 59), dtype=torch.float32, device=env.device)
+        f = (lambda: env.smart_state(0, out=out)) if name == "full obs" else (lambda: env.smart_state(0, so, out=out))
+        for _ in range(5): f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100): f()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 100 * 1e3
+        print("%-16s %-9s %6.1f us  %5.2f TB/s" % (lib, name, us, (420 + 2832) * 65536 / us / 1e6))
+    env.close()
