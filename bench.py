@@ -317,6 +317,8 @@ def main():
     ap.add_argument("--caller-actions", action="store_true", help="profiling runs: the MAIN leg runs the caller-supplied-actions path (per turn evg_random_actions into a tensor + evg_step); needs --turns-per-launch 1")
     ap.add_argument("--learner-seat", action="store_true", help="profiling runs: the MAIN leg runs the learner-seat path (per turn evg_random_actions_seat into a tensor + evg_step_vs_policy); needs --turns-per-launch 1")
     ap.add_argument("--opponent", default="random", help="the on-device bot of the learner-seat leg (a name from everglades_amd._lib.POLICY_NAMES); random = the headline's game mix")
+    ap.add_argument("--timing", default="torch", choices=["native", "torch"], help="single-rank timed region: launch duration from two pre-created torch events around an untimed call, one synchronisation in the closing bracket (default; 1.05-1.1 us per step of host time in the 20-step shape, "
+                         "tools/driver_shape_timing_ab.sh) or from the native driver's own events, read inside the call, which synchronises itself (1.2-4.7 us)")
     ap.add_argument("--pipeline", type=int, default=2, help="parts of the double-buffered leg (everglades_amd.PipelinedVecEnv)")
     ap.add_argument("--details", default="", help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
@@ -411,7 +413,7 @@ def main():
 
     if main_fused is True:
         rollout(args.steps, False, args.turns_per_launch, True, prepare=True)     # capture + instantiate the graphs of the K-step launch shape now (nothing is played)
-    if dist_on:      # torch creates an event at its first record(): not inside the timed region
+    if dist_on or args.timing == "torch":      # torch creates an event at its first record(): not inside the timed region
         ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         for ev in (ev0, ev1, ev2):
             ev.record()
@@ -420,10 +422,16 @@ def main():
     barrier()
     t0 = time.perf_counter()
     gathered = None
-    if not dist_on:
-        # HIP events around the step-kernel launches, recorded by the native driver on the stream it launches on and read after the last one (measured
-        # against torch events around an untimed call + one synchronisation: the lazily created torch events cost the 20-step shape 4 us per step)
+    if not dist_on and args.timing == "native":
+        # HIP events around the step-kernel launches, recorded by the native driver on the stream it launches on and read after the last one
         kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch, main_fused)
+    elif not dist_on:
+        # the launches are only ENQUEUED (no event read-out, no synchronisation inside the call); their duration is taken from two stream events (created and
+        # recorded once before the region: torch creates an event at its first record()) after the closing bracket, whose torch.cuda.synchronize() is then
+        # the one host wait of the timed region
+        ev0.record()
+        rollout(args.steps, False, args.turns_per_launch, main_fused)
+        ev1.record()
     else:
         # nothing between the launches and the collective waits for the host: the step kernels, the pack kernel and the gather are
         # enqueued back to back on the stream; the launches' duration is read from two stream events after the closing barrier
@@ -439,8 +447,9 @@ def main():
         barrier()
     dt_local = time.perf_counter() - t0
     collective_ms = None
-    if dist_on:
+    if dist_on or args.timing == "torch":
         kernel_ms_sum = ev0.elapsed_time(ev1)       # HIP events on the stream the step kernels run on (torch's current stream)
+    if dist_on:
         collective_ms = ev1.elapsed_time(ev2)
     if env.check_fault():                           # (never expected: a chunk hand-over fault of a launch plan; raises)
         raise SystemExit("fault")

@@ -1,3 +1,5 @@
+"""Diagnostic: the Smart_State feature kernel (evg_smart_state / evg_smart_state_seat) at 65 536 envs for two builds of the library side by side
+(libevg_base.so = a copy of an earlier libevg.so kept beside the working build): time per call and achieved bytes per second."""
 import sys, torch
 sys.path.insert(0, '.')
 import everglades_amd as evg
