@@ -251,11 +251,11 @@ def compact_line(full):
     def leg(l):
         if not l:
             return None
-        o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "launches_per_turn", "turns_per_launch", "parts") if k in l}
+        o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "turns_per_launch", "parts") if k in l}
         if l.get("learner_vs_bot"):
             o["learner_vs_bot"] = {k: _r(l["learner_vs_bot"][k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms")}
         if l.get("roofline"):
-            o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("bound", "achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}      # (peak and byte source: as in the main roofline object)
+            o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}      # (bound, peak, unit and byte source: as in the main roofline object)
         return o
 
     c = full["config"]
