@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run on the GPU box: rocprofv3 --kernel-trace --stats of EXACTLY the driver's command (python3 bench.py --gpus 1 --steps 20 --warmup 5), so that the kernel time in
+# its bench line (roofline.kernel_ms x 20) can be read against the profiler's duration of the timed 20-turn dispatch.  -> profiles/<name>_driver_shape_kernel_stats.csv
+set -o pipefail
+NAME=${1:-r04_f}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_${NAME}_driver
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $OUT/bench.json 2> $OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
+cd $R
+python3 - <<PY
+import csv, glob, json
+f = glob.glob("$OUT/stats/*/*_kernel_trace.csv")[0]
+rows = [(int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f))]
+rows.sort()
+pers = [(i, n, d) for i, n, d in rows if "evg_step_kernel<float, 64, true, false, false, false>" in n]
+line = json.loads([l for l in open("$OUT/bench.json") if l.startswith("{")][-1])
+stats = open(glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]).read().splitlines()
+out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs"',
+       '"# persistent step-kernel dispatches of the run, in order (ns): %s"' % " ".join(str(d) for _, _, d in pers),
+       '"# the LAST one is the timed 20-turn launch: %d ns = %.2f us per turn; the line of the same run says roofline.kernel_ms = %.5f (x 20 turns = %.1f us between the two stream events), ms_per_step = %.5f"'
+       % (pers[-1][2], pers[-1][2] / 20 / 1e3, line["roofline"]["kernel_ms"], line["roofline"]["kernel_ms"] * 20 * 1e3, line["ms_per_step"]),
+       '"# (the others: the 150-turn settle launch of the desynchronising window and the 5-turn warm-up launch; under the profiler every dispatch is serialised)"',
+       stats[0]] + [l for l in stats[1:] if "evg::" in l]
+open("profiles/${NAME}_driver_shape_kernel_stats.csv", "w").write("\n".join(out) + "\n")
+print("\n".join(out[:4]))
+PY
+mkdir -p gpurun_out/profiles_$NAME && cp profiles/${NAME}_driver_shape_kernel_stats.csv gpurun_out/profiles_$NAME/
