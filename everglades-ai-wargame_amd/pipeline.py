@@ -1,10 +1,11 @@
 """PipelinedVecEnv -- the double-buffered consumer of the Gym-shaped path.
 
 A synchronous `step(actions) -> obs` over the whole batch cannot overlap anything: the orders of turn t + 1 depend on all
-observations of turn t, so every launch starts when the previous one has retired, and a single-turn launch spends its first
-~12 us computing and its last ~14 us writing.  A consumer that splits its batch in halves CAN overlap: while
-its policy network runs on the observations of half A, half B steps, and one half's write-out runs under the other half's
-compute.  This class is that pattern as an API instead of a recipe: `pipeline` handles of num_envs / pipeline envs each (global
+observations of turn t, so every launch starts when the previous one has retired, and half of a single-turn launch is fixed cost --
+dispatch, one memory round trip for the state, the serial chain of one wavefront's turn, end of kernel (DESIGN.md section 6:
+14.5 of 27 us at 65 536 envs).  A consumer that splits its batch in halves CAN overlap: while its policy network runs on the
+observations of half A, half B steps, and one half's fixed costs run under the other half's compute (two halves free-running:
+25.5 us of stream time per turn of the whole batch instead of 28.2).  This class is that pattern as an API instead of a recipe: `pipeline` handles of num_envs / pipeline envs each (global
 env ids preserved: part i owns ids env_id_base + i * n ...), each with its own HIP stream, all writing into contiguous slices of ONE
 set of full-batch tensors, plus the two event waits per part that make the hand-over between the caller's stream (where the policy
 runs) and a part's stream correct.
