@@ -351,6 +351,38 @@ def test_turn_can_be_captured_in_a_hip_graph(evg, oracle_mod):
     env.close()
 
 
+def test_learner_seat_turn_can_be_captured_in_a_hip_graph(evg, oracle_mod):
+    """The consumer's whole turn -- its policy's kernels (here the stand-in generator) and evg_step_vs_policy with the bot inside -- captured once with
+    torch.cuda.graph and replayed: 60 replays == 60 oracle turns (observation of the caller's seat, scores, state)."""
+    import torch
+    N, seed, seat, pol = 3000, 9, 1, "bull_rush"
+    pid = evg.EvergladesVecEnv.POLICIES[pol]
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    env.reset()
+    o_obs = ora.reset()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            env.step_vs(pol, env.random_actions_seat(seat), seat=seat)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        env.step_vs(pol, env.random_actions_seat(seat), seat=seat)
+    for _ in range(60):
+        g.replay()
+    torch.cuda.synchronize()
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(62):
+        ora.scripted_actions(pid, 1 - seat, o_obs, oa)
+        oa[:, seat] = ora.random_actions()[:, seat]
+        o_obs, _, _, o_info = ora.step(oa)
+    assert np.array_equal(_np(env._obs_seat).astype(np.float64), o_obs[:, seat]) and np.array_equal(_np(env.scores), o_info["scores"])
+    check_state(env, ora.get_state(), "learner-seat turn replayed from a graph")
+    env.close()
+
+
 @pytest.mark.parametrize("shape", ["four_lane", "two_lane", "chunked"])
 def test_persistent_rollout_can_be_captured_in_a_hip_graph(evg, oracle_mod, shape):
     """The PERSISTENT form inside a caller's graph: a rollout launch (launch plan) only enqueues -- a chunked launch zeroes its queues and
