@@ -957,6 +957,17 @@ def test_ten_thousand_reference_matches_on_device(evg):
     st2 = env.episode_stats()
     assert np.array_equal(st2["winner"], d["winner"]) and np.array_equal(st2["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"])
     env.close()
+    # and through the learner-seat turn: the caller's seat takes its orders from a tensor (evg_random_actions_seat), the other seat is the on-device
+    # random_actions bot inside the step kernel (evg_step_vs_policy) -- on either seat the same 10 000 reference-played games
+    for seat in (0, 1):
+        env = evg.EvergladesVecEnv(n, seed=int(d["seed"][0]), env_id_base=0, auto_reset=False)
+        env.reset()
+        for _ in range(150):
+            so, rew, done, info = env.step_vs("random_actions", env.random_actions_seat(seat), seat=seat)
+        st3 = env.episode_stats()
+        assert int(done.sum()) == n and st3["totals"].tolist() == [n] + d["wins_p0_p1_tie"].tolist(), seat
+        assert np.array_equal(st3["winner"], d["winner"]) and np.array_equal(st3["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"]), seat
+        env.close()
 
 
 def test_ten_thousand_reference_matches_config5_on_device(evg):
@@ -987,6 +998,23 @@ def test_ten_thousand_reference_matches_config5_on_device(evg):
     st2 = env.episode_stats()
     assert np.array_equal(st2["winner"], d["winner"]) and np.array_equal(st2["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"])
     env.close()
+    # ... and through the learner-seat turn (evg_step_vs_policy), in both arrangements the reference's scripts use: the "learner" -- here the other bot's orders,
+    # computed by the standalone agent kernel from the ONE-SEAT observation tensor the turn returns -- on seat 0 with SwarmAgent inside the step kernel, and on
+    # seat 1 with Cycle_BRush_Turn25 inside.  Same 10 000 reference-played games, same winners, lengths and final scores.
+    import torch
+    for seat, learner, bot in ((0, "cycle_rush_turn25", "swarm"), (1, "swarm", "cycle_rush_turn25")):
+        env = evg.EvergladesVecEnv(n, seed=int(d["seed"][0]), env_id_base=0, auto_reset=False)
+        env.reset()
+        full = torch.zeros((n, 2, 105), dtype=torch.float32, device=env.device)
+        so = env.observe_seat(seat)
+        for _ in range(150):
+            full[:, seat] = so                                   # the agent kernel reads rows [:, seat] of a [N, 2, 105] tensor
+            rows = env.scripted_actions(learner, seat, obs=full)[:, seat].contiguous()
+            so, rew, done, info = env.step_vs(bot, rows, seat=seat)
+        st3 = env.episode_stats()
+        assert int(done.sum()) == n and st3["totals"].tolist() == [n] + d["wins_p0_p1_tie"].tolist(), (seat, st3["totals"])
+        assert np.array_equal(st3["winner"], d["winner"]) and np.array_equal(st3["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"]), seat
+        env.close()
 
 
 def _compare_whole_batch(env, ora, o_obs, what):
