@@ -292,6 +292,31 @@ def test_scripted_agents_golden_through_abi(evg):
         env.close()
 
 
+def test_learner_seat_turn_replays_the_references_agent_classes(evg):
+    """evg_step_vs_policy pinned by the REFERENCE, not by the oracle: in every pairing of tests/golden/agents_scripted.npz (the reference's own agent
+    classes on its own server, three consecutive episodes each) one seat's RECORDED orders are handed in as the caller's rows and the other seat's bot is
+    evaluated inside the step kernel from the on-chip state; the caller's observation after every turn, the final scores and the status must be the
+    fixture's -- for both choices of the caller's seat, i.e. every bot of the fixture is exercised on chip in the seat the reference played it in."""
+    import torch
+    d = load_golden("agents_scripted.npz")
+    G, E = d["length"].shape
+    for g in range(G):
+        pol = [int(x) for x in d["policy"][g]]
+        for seat in (0, 1):
+            env = evg.EvergladesVecEnv(1, seed=int(d["seed"][g]), env_id_base=int(d["env_id"][g]), obs_dtype="float64", auto_reset=False)
+            for ep in range(E):
+                env.reset()
+                so = env.observe_seat(seat)
+                for t in range(int(d["length"][g, ep])):
+                    assert np.array_equal(_np(so)[0], d["obs"][g, ep, t, seat].astype(np.float64)), (g, seat, ep, t)
+                    rows = torch.as_tensor(d["actions"][g, ep, t, seat].astype(np.int32), device=env.device).reshape(1, 7, 2)
+                    so, rew, done, info = env.step_vs(pol[1 - seat], rows, seat=seat)
+                assert int(done[0]) == 1 and int(info["status"][0]) == d["status"][g, ep], (g, seat, ep)
+                assert np.array_equal(_np(info["scores"])[0], d["scores"][g, ep]), (g, seat, ep)
+                assert np.array_equal(_np(so)[0], d["obs"][g, ep, int(d["length"][g, ep]), seat].astype(np.float64)), (g, seat, ep, "final")
+            env.close()
+
+
 @pytest.mark.parametrize("N,seats", [(1024, ("cycle_rush_turn25", "swarm")), (1024, ("swarm", "cycle_rush_turn50")), (65536, ("cycle_rush_turn25", "swarm"))])
 def test_config5_scripted_rollout_vs_oracle(evg, oracle_mod, N, seats):
     """BASELINE config 5: cycle_base_rush vs swarm_agent action streams with auto-reset (games end by BaseCapture
