@@ -23,7 +23,7 @@ POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "al
                 "random_actions_delay", "same_commands"]      # index = EVG_POLICY_* of include/evg.h (agents/State_Machine/<name>.py)
 POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
-EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat", "evg_random_actions_seat", "evg_smart_state_seat", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war", "evg_sightings", "evg_smart_state", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
+EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat", "evg_random_actions_seat", "evg_smart_state_seat", "evg_smart_state_compact", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war", "evg_sightings", "evg_smart_state", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
            "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_pack_episode_results_counted", "evg_launch_plan", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
@@ -115,6 +115,7 @@ def load(path=None):
     L.evg_observe_seat.argtypes = [vp, C.c_int, vp, vp]
     L.evg_random_actions_seat.argtypes = [vp, C.c_int, vp, vp]
     L.evg_smart_state_seat.argtypes = [vp, vp, vp, vp]
+    L.evg_smart_state_compact.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.evg_check_fault.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.evg_rollout_vs_policy.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_float), vp]
     L.evg_fog_of_war.argtypes = [vp, vp, vp, vp]

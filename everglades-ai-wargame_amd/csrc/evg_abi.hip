@@ -673,7 +673,7 @@ int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_
     if (!h || !obs || !features_out || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
     if ((reinterpret_cast<uintptr_t>(features_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "features_out must be 16-byte aligned");
     EVG_ON_DEVICE(h);
-    const int rc = launch_smart_state(h->S, player, obs, 0, features_out, h->cfg.obs_dtype, stream);
+    const int rc = launch_smart_state(h->S, player, obs, 0, features_out, nullptr, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }
@@ -682,7 +682,17 @@ int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_ou
     if (!h || !obs_seat || !features_out) return fail(EVG_ERR_INVALID, "bad argument");
     if ((reinterpret_cast<uintptr_t>(features_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "features_out must be 16-byte aligned");
     EVG_ON_DEVICE(h);
-    const int rc = launch_smart_state(h->S, 0, obs_seat, 1, features_out, h->cfg.obs_dtype, stream);
+    const int rc = launch_smart_state(h->S, 0, obs_seat, 1, features_out, nullptr, h->cfg.obs_dtype, stream);
+    if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+int evg_smart_state_compact(evg_handle* h, int player, const void* obs, float* shared_out, float* swarm_out, void* stream) {
+    if (!h || !obs || !shared_out || !swarm_out || player < -1 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
+    if ((reinterpret_cast<uintptr_t>(shared_out) & 7u) != 0 || (reinterpret_cast<uintptr_t>(swarm_out) & 15u) != 0)
+        return fail(EVG_ERR_INVALID, "shared_out must be 8-byte, swarm_out 16-byte aligned");
+    EVG_ON_DEVICE(h);
+    const int rc = launch_smart_state(h->S, player < 0 ? 0 : player, obs, player < 0 ? 1 : 0, shared_out, swarm_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
 }

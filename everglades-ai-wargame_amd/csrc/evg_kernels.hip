@@ -1636,8 +1636,14 @@ __global__ void __launch_bounds__(256) evg_fog_kernel(DevState S, uint8_t* fog, 
 // -> features float32 [N][12][59] (the reference builds float64 and the network casts to float32: computed in f64,
 // rounded once).
 // ---------------------------------------------------------------------------------------------
-template <typename OT>
-__global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player, int seat_only, const OT* obs, float* out) {
+// COMPACT (evg_smart_state_compact): the same values without their redundancy.  34 of the 59 features of a swarm are the same for all 12 swarms of an env and
+// 12 more are the constant one-hot swarm id, so the 12 x 59 matrix is determined by `shared` [34] and `swarm` [12][13] = {one-hot node (11), average
+// health x alive / 1000, in transit}: 760 B per env instead of 2 832.  (A consumer's first linear layer over the 59 inputs is W[:, :34] shared + W[:, 34:47] swarm
+// + W[:, 47 + s]: the same numbers from a quarter of the bytes.)  With so little to write the kernel is no longer bound by bytes but by the ~200 instructions a
+// wavefront spends per env (23 us at 65 536 envs against 40 for the full matrix).  A mapping of eight envs per wavefront with per-lane element descriptors was built
+// and measured: 38 us -- every element then costs ~18 instructions (two LDS reads, the float64 product, selects) where the table costs one read; dropped.
+template <typename OT, bool COMPACT = false>
+__global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player, int seat_only, const OT* obs, float* out, float* out_swarm) {
     // One wavefront per env and pass.  The 105-value observation row is staged in LDS once; every distinct output value of the
     // env goes into a small per-wave table -- the 34 features all swarms share and the 12 per-swarm health features are
     // one IEEE f64 division each (46 lanes: one division sequence per env instead of one per output element), then the
@@ -1671,20 +1677,23 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
         row[w][lane + 64] = (live && lane + 64 < OBS) ? (int)o[lane + 64] : 0;
         WAVE_SYNC();
         const int* r = row[w];
-        double num = 0.0, den = 1.0;
-        if (lane == 0) { num = (double)r[0]; den = 150.0; }                                          // :280
-        else if (lane < 12) { num = (double)r[3 + 4 * (lane - 1)]; den = 100.0; }                    // :282
-        else if (lane < 23) { num = (double)r[4 + 4 * (lane - 12)]; den = 100.0; }                   // :284
+        // float32(n / d) of the reference's float64 quotient, taken as float32(n * (1 / d)): the float64 product differs from the quotient by an ulp of float64
+        // at most, which never crosses a float32 rounding boundary for any numerator these features can have (turn 0..255, control -511..511, units 0..200,
+        // groups 0..12, health x alive 0..1 663: checked exhaustively in tests/test_abi_and_host.py) -- one multiplication instead of a division sequence per env
+        double num = 0.0, rcp = 1.0;
+        if (lane == 0) { num = (double)r[0]; rcp = 1.0 / 150.0; }                                    // :280
+        else if (lane < 12) { num = (double)r[3 + 4 * (lane - 1)]; rcp = 1.0 / 100.0; }              // :282
+        else if (lane < 23) { num = (double)r[4 + 4 * (lane - 12)]; rcp = 1.0 / 100.0; }             // :284
         else if (lane < 34) {                                                                       // :200-213, :286
             int cnt = 0;
 #pragma unroll
             for (int k = 0; k < NG; ++k) cnt += (r[48 + 5 * k] == 0 && r[45 + 5 * k] - 1 == lane - 23) ? 1 : 0;
-            num = (double)cnt; den = 12.0;
+            num = (double)cnt; rcp = 1.0 / 12.0;
         } else if (lane < 46) {                                                                     // :294, swarm lane - 34
             const int sw = lane - 34;
-            num = (double)r[47 + 5 * sw] * (double)r[49 + 5 * sw]; den = 1000.0;
+            num = (double)(r[47 + 5 * sw] * r[49 + 5 * sw]); rcp = 1.0 / 1000.0;
         }
-        if (lane < 46) tab[w][lane] = (float)(num / den);
+        if (lane < 46) tab[w][lane] = (float)(num * rcp);
         if (lane < NG) tab[w][T_MOV + lane] = (float)r[48 + 5 * lane];                                // :296
 #pragma unroll
         for (int t = lane; t < NG * NN; t += 64) {                                                    // :288-292
@@ -1692,6 +1701,23 @@ __global__ void __launch_bounds__(256) evg_smart_state_kernel(int N, int player,
             tab[w][T_HOT + t] = (r[45 + 5 * sw] == n + 1) ? 1.f : 0.f;
         }
         WAVE_SYNC();
+        if constexpr (COMPACT) {
+            constexpr int SF = 13, SV = NG * SF / 4;                                                  // 156 floats = 39 float4 per env
+            static_assert(NG * SF % 4 == 0 && T_HP % 2 == 0, "whole vectors");
+            if (live) {
+                if (lane < T_HP / 2)                                                                  // shared [34]: 17 float2 (136 B per env: 8-byte aligned rows)
+                    reinterpret_cast<float2*>(out + (size_t)e * T_HP)[lane] = make_float2(tab[w][2 * lane], tab[w][2 * lane + 1]);
+                if (lane < SV) {
+                    float v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int j = 4 * lane + c, sw = j / SF, f = j - sw * SF;
+                        v[c] = tab[w][f < NN ? T_HOT + sw * NN + f : (f == NN ? T_HP + sw : T_MOV + sw)];
+                    }
+                    reinterpret_cast<float4*>(out_swarm + (size_t)e * NG * SF)[lane] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        } else
         if (live) {
             float4* dst = reinterpret_cast<float4*>(out + (size_t)e * NG * F);                        // 2 832 B per env: 16-byte aligned rows
 #pragma unroll
@@ -1985,14 +2011,20 @@ int launch_scripted_reset(const DevState& S, void* stream) {
     return (int)hipGetLastError();
 }
 
-int launch_smart_state(const DevState& S, int player, const void* obs, int seat_only, float* out, int obs_dtype, void* stream) {
+int launch_smart_state(const DevState& S, int player, const void* obs, int seat_only, float* out, float* out_swarm /* non-NULL: compact form, out = shared [N][34] */, int obs_dtype, void* stream) {
     const int blocks = (S.N + 3) / 4;                       // one wavefront per env and pass; 8 blocks per CU resident, further envs in passes
     const dim3 grid((unsigned)(blocks < 2048 ? blocks : 2048)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (obs_dtype) {
-        case EVG_OBS_F32: hipLaunchKernelGGL(evg_smart_state_kernel<float>, grid, block, 0, s, S.N, player, seat_only, (const float*)obs, out); break;
-        case EVG_OBS_F64: hipLaunchKernelGGL(evg_smart_state_kernel<double>, grid, block, 0, s, S.N, player, seat_only, (const double*)obs, out); break;
-        case EVG_OBS_I16: hipLaunchKernelGGL(evg_smart_state_kernel<int16_t>, grid, block, 0, s, S.N, player, seat_only, (const int16_t*)obs, out); break;
+        case EVG_OBS_F32: if (out_swarm) hipLaunchKernelGGL((evg_smart_state_kernel<float, true>), grid, block, 0, s, S.N, player, seat_only, (const float*)obs, out, out_swarm);
+                          else hipLaunchKernelGGL((evg_smart_state_kernel<float, false>), grid, block, 0, s, S.N, player, seat_only, (const float*)obs, out, out_swarm);
+                          break;
+        case EVG_OBS_F64: if (out_swarm) hipLaunchKernelGGL((evg_smart_state_kernel<double, true>), grid, block, 0, s, S.N, player, seat_only, (const double*)obs, out, out_swarm);
+                          else hipLaunchKernelGGL((evg_smart_state_kernel<double, false>), grid, block, 0, s, S.N, player, seat_only, (const double*)obs, out, out_swarm);
+                          break;
+        case EVG_OBS_I16: if (out_swarm) hipLaunchKernelGGL((evg_smart_state_kernel<int16_t, true>), grid, block, 0, s, S.N, player, seat_only, (const int16_t*)obs, out, out_swarm);
+                          else hipLaunchKernelGGL((evg_smart_state_kernel<int16_t, false>), grid, block, 0, s, S.N, player, seat_only, (const int16_t*)obs, out, out_swarm);
+                          break;
         default: return -1;
     }
     return (int)hipGetLastError();

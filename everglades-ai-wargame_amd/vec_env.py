@@ -307,6 +307,34 @@ class EvergladesVecEnv(object):
         self._check(self.L.evg_smart_state(self._h, int(player), self._ptr(obs), self._ptr(out), self._stream()))
         return out
 
+    def smart_state_compact(self, player, obs=None, shared=None, swarm=None):
+        """The Smart_State features without their redundancy (evg_smart_state_compact): (shared float32 [N, 34], swarm float32 [N, 12, 13]) with
+        features[e, s] == cat(shared[e], swarm[e, s], onehot(s)) value for value -- 760 B per env instead of 2 832.  `obs` as in smart_state():
+        the env's observation buffer, a [N, 2, 105] tensor (rows of seat `player`) or a one-seat tensor [N, 105]."""
+        torch = _torch()
+        obs = self.obs if obs is None else obs
+        if shared is None:
+            shared = torch.empty((self.num_envs, 34), dtype=torch.float32, device=self.device)
+        if swarm is None:
+            swarm = torch.empty((self.num_envs, _lib.NUM_GROUPS, 13), dtype=torch.float32, device=self.device)
+        self._user(shared, (self.num_envs, 34), torch.float32, "shared")
+        self._user(swarm, (self.num_envs, _lib.NUM_GROUPS, 13), torch.float32, "swarm")
+        if isinstance(obs, torch.Tensor) and obs.dim() == 2:
+            self._user(obs, (self.num_envs, _lib.OBS_LEN), self.obs_dtype, "obs")
+            player = -1
+        else:
+            self._user(obs, (self.num_envs, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
+        self._check(self.L.evg_smart_state_compact(self._h, int(player), self._ptr(obs), self._ptr(shared), self._ptr(swarm), self._stream()))
+        return shared, swarm
+
+    @staticmethod
+    def expand_smart_state(shared, swarm):
+        """[N, 12, 59] from the compact pair (for checks; a consumer would rather split its first layer's weights)."""
+        torch = _torch()
+        n = shared.shape[0]
+        eye = torch.eye(_lib.NUM_GROUPS, dtype=shared.dtype, device=shared.device).expand(n, -1, -1)
+        return torch.cat([shared[:, None, :].expand(-1, _lib.NUM_GROUPS, -1), swarm, eye], dim=2)
+
     @staticmethod
     def move_table():
         """int32 [11, 5]: Move_Translation.get_move(node0, direction) as a lookup table (directions left, right, up, down, stay)."""

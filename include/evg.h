@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define EVG_ABI_VERSION 4      /* 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat,
-                                  evg_check_fault + EVG_ERR_FAULT, evg_pack_episode_results_counted, evg_config.cache_mib; 3: evg_launch_plan; 2: evg_pack_episode_results, node words as u32 */
+                                  evg_smart_state_compact, evg_check_fault + EVG_ERR_FAULT, evg_pack_episode_results_counted, evg_config.cache_mib; 3: evg_launch_plan; 2: evg_pack_episode_results, node words as u32 */
 
 /* The ABI is exactly the functions declared in this header: the library is built with -fvisibility=hidden and only they are exported. */
 #define EVG_API __attribute__((visibility("default")))
@@ -207,6 +207,14 @@ EVG_API int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream);
 EVG_API int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream);
 /* The same features from a one-seat observation tensor (device [N][105], as evg_step_vs_policy / evg_observe_seat write it). */
 EVG_API int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_out, void* stream);
+/* The same features without their redundancy (what a bandwidth-bound consumer wants: the full matrix is 2 832 B per env, 185 MB per call at 65 536 envs).
+ * Of the 59 features of a swarm, 34 are the same for all 12 swarms of an env ({turn/150, 11 x control/100, 11 x enemy units/100, 11 x idle allied groups/12})
+ * and 12 are the constant one-hot swarm id; the matrix is therefore determined by
+ *   shared_out  device float [N][34]       (8-byte aligned)   = features[e][s][0:34] for any s
+ *   swarm_out   device float [N][12][13]   (16-byte aligned)  = features[e][s][34:47] = {one-hot node (11), avg health x alive / 1000, in transit}
+ * (760 B per env); features[e][s] = shared[e] ++ swarm[e][s] ++ onehot(s), value for value what evg_smart_state writes.  player 0 / 1: obs is
+ * [N][2][105]; player -1: obs is a one-seat tensor [N][105]. */
+EVG_API int evg_smart_state_compact(evg_handle* h, int player, const void* obs, float* shared_out, float* swarm_out, void* stream);
 EVG_API void evg_move_table(int32_t* table);
 
 /* Input generator for the benchmark configs: the on-device equivalent of

@@ -240,6 +240,14 @@ def test_reward_by_reciprocal_equals_the_division_in_float32():
     assert np.array_equal((s / 3700.0).astype(np.float32), (s * np.float64(1.0 / 3700.0)).astype(np.float32))
 
 
+def test_smart_state_quotients_by_reciprocal_equal_the_division_in_float32():
+    """csrc/evg_kernels.hip (evg_smart_state_kernel) takes float32(n / d) of the reference's float64 features (DQNAgent.py:280-294) as float32(n * (1 / d)):
+    equal for EVERY numerator the features can have -- turn / 150, control / 100, units / 100, idle groups / 12, average health x alive / 1000."""
+    for lo, hi, den in ((0, 256, 150.0), (-511, 512, 100.0), (0, 201, 100.0), (0, 13, 12.0), (0, 128 * 13, 1000.0)):
+        n = np.arange(lo, hi).astype(np.float64)
+        assert np.array_equal((n / den).astype(np.float32), (n * (1.0 / den)).astype(np.float32)), den
+
+
 def test_bench_window_helpers():
     """bench.py's desynchronising pre-roll: the episode phase of a global env id is the same function on the device (torch) and
     in the CPU replay (numpy), covers 0..149 about uniformly and is unrelated between neighbouring envs; the hash that ties

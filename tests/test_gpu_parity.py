@@ -514,6 +514,12 @@ def test_smart_state_features_match_reference_fixture(evg):
         for p in range(2):
             f = _np(env.smart_state(p, obs))
             assert np.array_equal(f, d["features"][:, p].astype(np.float32)), (dt, p)
+            # the compact pair (shared [34] + per-swarm [13], 760 B per env instead of 2 832) expands to the same matrix, value for value
+            sh, sw = env.smart_state_compact(p, obs)
+            assert sh.shape == (M, 34) and sw.shape == (M, 12, 13)
+            assert np.array_equal(_np(evg.EvergladesVecEnv.expand_smart_state(sh, sw)), d["features"][:, p].astype(np.float32)), (dt, p, "compact")
+            sh1, sw1 = env.smart_state_compact(p, obs[:, p].contiguous())          # from a one-seat tensor
+            assert torch.equal(sh, sh1) and torch.equal(sw, sw1)
         env.close()
 
 
@@ -529,6 +535,7 @@ def test_smart_state_multi_pass_ragged_vs_oracle(evg, oracle_mod):
         got = _np(env.smart_state(p))
         want = oracle_mod.smart_state(obs[:, p]).astype(np.float32)
         assert got.shape == (N, 12, 59) and np.array_equal(got, want), p
+        assert np.array_equal(_np(evg.EvergladesVecEnv.expand_smart_state(*env.smart_state_compact(p))), want), (p, "compact")
     env.close()
 
 

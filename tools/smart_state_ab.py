@@ -3,7 +3,8 @@
 import sys, torch
 sys.path.insert(0, '.')
 import everglades_amd as evg
-for lib in ("libevg_base.so", "libevg.so"):
+import os
+for lib in [l for l in ("libevg_base.so", "libevg.so") if os.path.exists("everglades-ai-wargame_amd/" + l)]:
     env = evg.EvergladesVecEnv(65536, seed=3, auto_reset=True, library="everglades-ai-wargame_amd/" + lib)
     env.reset(); env.rollout_random(60, turns_per_launch=60)
     so = env.observe_seat(0)
@@ -18,4 +19,16 @@ for lib in ("libevg_base.so", "libevg.so"):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 100 * 1e3
         print("%-16s %-9s %6.1f us  %5.2f TB/s" % (lib, name, us, (420 + 2832) * 65536 / us / 1e6))
+    if hasattr(env.L, "evg_smart_state_compact"):
+        sh = torch.empty((65536, 34), dtype=torch.float32, device=env.device); sw = torch.empty((65536, 12, 13), dtype=torch.float32, device=env.device)
+        for name, src in (("full obs", None), ("seat obs", so)):
+            f = lambda: env.smart_state_compact(0, src, shared=sh, swarm=sw)
+            for _ in range(5): f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100): f()
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 100 * 1e3
+            print("%-16s %-9s %6.1f us  %5.2f TB/s   (compact: shared [34] + swarm [12][13])" % (lib, name, us, (420 + 760) * 65536 / us / 1e6))
     env.close()
