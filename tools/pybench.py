@@ -12,7 +12,9 @@ for N in (64, 65536):
     env.reset()
     a = env.random_actions()
     torch.cuda.synchronize()
-    for name, fn in (("random_actions+step", lambda: env.step(env.random_actions())), ("step only", lambda: env.step(a))):
+    rows = env.random_actions_seat(0)
+    for name, fn in (("random_actions+step", lambda: env.step(env.random_actions())), ("step only", lambda: env.step(a)),
+                     ("random_actions_seat+step_vs", lambda: env.step_vs("swarm", env.random_actions_seat(0))), ("step_vs only", lambda: env.step_vs("swarm", rows))):
         for _ in range(50):
             fn()
         torch.cuda.synchronize()
