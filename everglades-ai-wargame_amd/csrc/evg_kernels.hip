@@ -445,9 +445,11 @@ __global__ void __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 #ifdef EVG_DIAG      // experiment knobs (tools/stagger.py): delay = slot x a + simd x b sleeps of 64 cycles, a = ablate[15:8] - 1, b = ablate[23:16]
-    const int kStaggerSlot = (A->io_.ablate >> 8) & 0xFFu ? (int)((A->io_.ablate >> 8) & 0xFFu) - 1 : 84, kStaggerSimd = (int)((A->io_.ablate >> 16) & 0xFFu);
+    const int kStaggerSlot = (A->io_.ablate >> 8) & 0xFFu ? (int)((A->io_.ablate >> 8) & 0xFFu) - 1 : 67, kStaggerSimd = (int)((A->io_.ablate >> 16) & 0xFFu);
 #else
-    constexpr int kStaggerSlot = 84, kStaggerSimd = 0;      // x 64 cycles (s_sleep 1)
+    constexpr int kStaggerSlot = 67, kStaggerSimd = 0;      // x 64 cycles (s_sleep 1).  Round-4 sweep of the final kernel (profiles/r04_f_stagger_single_turn.txt): a plateau from
+                                                            // 59 to 75 x 64 cycles (26.8 us per launch), 27.5 at round 3's 84, 27.8-29.5 below 55 and above 100, 28.9 without
+
 #endif
     // ---- prologue loads: the constant tables (one blob, already in its LDS layout) and this lane's state (env fastest; the two player rows of a group index interleave
     // across lanes).  Every load is issued before the first LDS store, so the launch pays ONE memory round trip here
