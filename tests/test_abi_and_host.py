@@ -322,5 +322,5 @@ def test_bench_stdout_line_is_compact_and_complete():
     # what a first multi-GPU line is read against: N x the committed one-rank RCCL rehearsal of the same shape, next to the one-GPU line of that shape
     exp = bench.expected_if_wire_free(8, 20)
     assert exp and "r04_f_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
-    assert 0.7 < exp["weak_scaling_efficiency_if_wire_free"] < 1.15 and exp["collective_us_1rank"] > 0      # (two single samples of a 0.4 ms region: +-8 % from run to run)
+    assert 0.7 < exp["weak_scaling_efficiency_if_wire_free"] < 1.0 and exp["collective_us_1rank"] > 0       # step launches / (step launches + collective path), one run
     assert bench.expected_if_wire_free(8, 12345) is None
