@@ -35,7 +35,6 @@ results (one RCCL gather to rank 0 over xGMI, 16 bytes per env).  Rank 0 prints 
 """
 import argparse
 import glob
-import hashlib
 import json
 import os
 import sys
@@ -84,13 +83,10 @@ def usable_cores():
 
 def kernel_source_hash():
     """Identifies the kernel sources the running libevg.so was built from (build() rebuilds it from them): the committed
-    counter passes under profiles/ carry the same hash, and figures from another build are not used."""
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc")      # the files the product kernels are compiled from
-    for f in [os.path.join(csrc, n) for n in ("evg_device.h", "evg_kernels.hip", "evg_step4.inc", "evg_mt.h", "evg_rng.h")] + [os.path.join(ROOT, "include", "evg.h")]:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    counter passes under profiles/ carry the same hash, and figures from another build are not used.  (One definition, shared with
+    tools/_prof.py: everglades_amd._lib.kernel_source_hash.)"""
+    import everglades_amd
+    return everglades_amd._lib.kernel_source_hash()
 
 
 def committed_counters(kind, n_local, workload, obs_dtype, variant=None):
@@ -231,25 +227,26 @@ def compact_line(full):
     def roof(r):
         if not r:
             return None
-        keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "bytes_per_env_step", "bytes_source", "launch_form", "launches_timed",
-                "turns_per_launch_timed", "kernel_launches_per_rollout_launch", "bound_is", "note")
+        keep = ("bound", "bound_contract", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "bytes_per_env_step", "bytes_source", "launch_form", "launches_timed",
+                "turns_per_launch_timed", "kernel_launches_per_rollout_launch", "survey_8d_frac", "hbm_proper_frac", "hbm_proper_source", "note")
         o = {k: _r(r[k], 5) for k in keep if k in r and r[k] is not None}
         if "traffic" not in o:
             o["traffic"] = None
-        if "bound_is" in o:
-            o["bound_is"] = "fabric L2<->InfinityCache/HBM, round's working set cache-resident; HBM proper: beyond_mall"
+        if r.get("bound") == "fabric":
+            o["bound_is"] = "L2<->InfinityCache/HBM requests; a round's working set is cache-resident, so not all DRAM; hbm_proper_frac = same kernel cycled beyond the cache"
+        if "survey_8d_frac" in o:
+            o["survey_8d_note"] = "SURVEY 8(d) byte model (4530 B/env-step) at this kernel time; >1 = model not applicable to the persistent form (state stays on chip)"
         if "note" in o:
             o["note"] = "working set cache-resident: latency/issue-bound, frac meaningless"
         if "kernel" in r:
             o["kernel"] = r["kernel"].split(" | ")[0][:160]
         bm = r.get("beyond_mall")
         if bm:
-            c = bm.get("whole_batch_cycled_every_few_chunks") or {}
-            w = (bm.get("whole_rounds_one_after_the_other") or {}).get("persistent") or {}
-            o["beyond_mall"] = {"envs": bm["envs"], "working_set_MB": bm["working_set_MB"], "frac_in_rounds_of_cache_size": _r(w.get("frac_of_8TBps")),
-                                "hbm_frac_beyond_the_infinity_cache": _r(bm.get("hbm_frac_beyond_the_infinity_cache")),
-                                "ns_per_env_step_rounds_cycled_65536": [_r(w.get("ns_per_env_step")), _r(c.get("ns_per_env_step")), _r(c.get("ns_per_env_step_at_65536") or w.get("ns_per_env_step_at_65536"))],
-                                "sources": [x for x in (w.get("source"), c.get("source")) if x]}
+            o["beyond_mall"] = {k: {"envs": v.get("envs", bm.get("envs")), "working_set_MB": v.get("working_set_MB", bm.get("working_set_MB")), "frac": _r(v["frac_of_8TBps"]), "ns_per_env_step": _r(v["ns_per_env_step"]), "source": v["source"]}
+                                for k, v in bm.items() if isinstance(v, dict) and "frac_of_8TBps" in v}
+            w = (bm.get("whole_rounds_one_after_the_other") or {}).get("persistent")
+            if w:
+                o["beyond_mall"]["whole_rounds_262144_envs"] = {"frac": _r(w["frac_of_8TBps"]), "ns_per_env_step": _r(w["ns_per_env_step"]), "source": w["source"]}
         return o
 
     def leg(l):
@@ -276,19 +273,23 @@ def compact_line(full):
                      "obs_float64": leg(c.get("obs_float64")),
                      "without_observations": leg(c.get("without_observations"))}
     out["roofline"] = roof(full["roofline"])
+    if "timing" in full:
+        t = full["timing"]
+        out["timing"] = {"repeats": t["repeats"], "reported": t["reported"], "min_ms_per_step": _r(t["min_ms_per_step"], 5), "max_ms_per_step": _r(t["max_ms_per_step"], 5),
+                         "min_value": _r(t["min_value"], 5), "max_value": _r(t["max_value"], 5)}
     if "roofline_valu_issue" in full:
         v = full["roofline_valu_issue"]
         out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "valu_insts_per_wave_turn", "source")}
     if "distributed" in full:
         d = dict(full["distributed"])
-        d["collective"] = "pack(rows+win counts) + gather to rank 0 + all_reduce(win counts) = closing barrier"
+        d["collective"] = "pack kernel + ONE gather to rank 0 (= closing bracket); win-count self-check after the region"
         for k in ("collective_us_is", "closing_bracket", "rows_expected_per_rank"):
             d.pop(k, None)
         pr = d.get("per_rank") or []          # per rank, as columns (rank = position): an 8-rank line must still fit a driver's tail
         d["per_rank"] = {k: [_r(r[k], 4) for r in pr] for k in ("seconds", "kernel_ms_per_step", "collective_us")}
         if d.get("expected"):
             d["expected"] = {k: _r(v, 5) for k, v in d["expected"].items() if k in ("value_if_wire_free", "per_gpu", "weak_scaling_efficiency_if_wire_free", "collective_us_1rank")}
-        for k in ("collective_us", "step_launches_us"):
+        for k in ("collective_us", "step_launches_us", "step_share_of_region"):
             d[k] = _r(d.get(k), 5)
         out["distributed"] = d
     if "cpu_baseline" in full:
@@ -323,6 +324,8 @@ def main():
     ap.add_argument("--opponent", default="random", help="the on-device bot of the learner-seat leg (a name from everglades_amd._lib.POLICY_NAMES); random = the headline's game mix")
     ap.add_argument("--timing", default="torch", choices=["native", "torch"], help="single-rank timed region: launch duration from two pre-created torch events around an untimed call, one synchronisation in the closing bracket (default; 1.05-1.1 us per step of host time in the 20-step shape, "
                          "tools/driver_shape_timing_ab.sh) or from the native driver's own events, read inside the call, which synchronises itself (1.2-4.7 us)")
+    ap.add_argument("--repeats", type=int, default=0, help="how often the exact K-step region is timed (value = the median region); 0 = auto: 9 when K x the measured step time < 50 ms, else 1")
+    ap.add_argument("--cache-mib", type=int, default=0, help="profiling runs: evg_config.cache_mib of the handle (the memory-side cache budget a chunked rollout launch may cycle through; 0 = the device's)")
     ap.add_argument("--pipeline", type=int, default=2, help="parts of the double-buffered leg (everglades_amd.PipelinedVecEnv)")
     ap.add_argument("--details", default="", help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
@@ -369,8 +372,8 @@ def main():
 
     def barrier():
         """barrier + torch.cuda.synchronize(): the opening bracket drains the device first so that every rank enters the barrier idle.  (The CLOSING
-        bracket of the N > 1 timed region is the all-reduce of the ranks' win counts -- a barrier that carries the self-check's payload -- followed
-        by one torch.cuda.synchronize(): two RCCL launches behind the step kernels, gather + all-reduce, instead of three.)"""
+        bracket of the N > 1 timed region is the path's one collective itself -- the gather to rank 0, which cannot complete before every rank has
+        played its steps and packed its rows -- followed by one torch.cuda.synchronize(); the job's time is the max over ranks.)"""
         torch.cuda.synchronize(device)
         if dist_on:
             dist.barrier(device_ids=[dev_index]) if args.backend == "nccl" else dist.barrier()
@@ -379,7 +382,7 @@ def main():
     def make_env(obs_dtype):
         """A handle in the desynchronised steady state + its rollout function (nsteps, timed, turns per launch) -> kernel ms sum."""
         env = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed, env_id_base=first, obs_dtype=obs_dtype, auto_reset=True, library=args.library,
-                                   diag=dict(lanes=args.diag_lanes) if args.diag_lanes else None)
+                                   diag=dict(lanes=args.diag_lanes) if args.diag_lanes else None, cache_mib=args.cache_mib)
         env.reset()
 
         def rollout(nsteps, timed, tpl, fused=True, observe=True, prepare=False):
@@ -397,89 +400,115 @@ def main():
             return out[-1] * nsteps if timed else 0.0
 
         desynchronise(env, first, args.workload, rollout)
-        rollout(PHASES, True, args.turns_per_launch, main_fused)   # settle: one more episode length in the launch form that is timed (also creates its timing events)
-        return env, rollout
+        settle = rollout(PHASES, True, args.turns_per_launch, main_fused)   # settle: one more episode length in the launch form that is timed (also creates its timing events)
+        return env, rollout, settle
 
     main_fused = "learner" if args.learner_seat else (not args.caller_actions)   # --caller-actions / --learner-seat (profiling runs): the main leg itself pays two launches per turn
     if (args.caller_actions or args.learner_seat) and args.turns_per_launch != 1:
         raise SystemExit("--caller-actions / --learner-seat need --turns-per-launch 1 (orders from a tensor exist in the single-turn form only)")
-    env, rollout = make_env(args.obs_dtype)
+    env, rollout, settle_ms = make_env(args.obs_dtype)
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
     gather = evg.ResultGather(n_local, total, device, force=dist_on)   # preallocated buffers; rank 0 receives (one RCCL gather)
     win_counts_dev = torch.zeros(4, dtype=torch.int64, device=device)       # filled by the pack kernel: win bookkeeping of this rank's own rows
-    if dist_on:      # first use opens the RCCL channels (gather and all-reduce): not part of the timed region
-        gather(env.packed_episode_results(out=gather.buffer, counts=win_counts_dev))
-        warm = win_counts_dev.clone() if args.backend == "nccl" else win_counts_dev.cpu()
-        dist.all_reduce(warm)
+    if dist_on:      # first use opens the RCCL channels of the gather: not part of the timed region
+        gather(env.packed_episode_results(out=gather.buffer))
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch, main_fused)
         played += args.warmup
 
     if main_fused is True:
         rollout(args.steps, False, args.turns_per_launch, True, prepare=True)     # capture + instantiate the graphs of the K-step launch shape now (nothing is played)
-    if dist_on or args.timing == "torch":      # torch creates an event at its first record(): not inside the timed region
-        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        for ev in (ev0, ev1, ev2):
-            ev.record()
-    # ---- timed region: exactly K steps; with more than one rank the path's one collective (the gather of episode results) is
-    # inside it (a single rank has nothing to exchange: its results are already where rank 0 reads them)
-    barrier()
-    t0 = time.perf_counter()
+
+    # ---- how often the exact K-step region is timed.  A region of a few hundred microseconds (the driver's --steps 20: 0.4 ms) is ONE draw from a
+    # distribution whose box-to-box and run-to-run spread is +-8 %: when K x (the step time the settle launches just showed) is below 50 ms the region is
+    # repeated R = 9 times -- each repeat bracketed exactly like the single region (barrier + synchronize on both sides, nothing else inside) -- and
+    # value / ms_per_step come from the MEDIAN region; min and max are reported next to it.  --repeats N forces N (profiling runs: 1).
+    est_ms_per_step = settle_ms / PHASES if settle_ms > 0 else 0.02
+    repeats = args.repeats if args.repeats > 0 else (9 if args.steps * est_ms_per_step < 50.0 else 1)
+    use_events = dist_on or args.timing == "torch"
+    if use_events:      # torch creates an event at its first record(): not inside the timed region
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(repeats)]
+        for tri in evs:
+            for ev in tri:
+                ev.record()
     gathered = None
-    if not dist_on and args.timing == "native":
-        # HIP events around the step-kernel launches, recorded by the native driver on the stream it launches on and read after the last one
-        kernel_ms_sum = rollout(args.steps, True, args.turns_per_launch, main_fused)
-    elif not dist_on:
-        # the launches are only ENQUEUED (no event read-out, no synchronisation inside the call); their duration is taken from two stream events (created and
-        # recorded once before the region: torch creates an event at its first record()) after the closing bracket, whose torch.cuda.synchronize() is then
-        # the one host wait of the timed region
-        ev0.record()
-        rollout(args.steps, False, args.turns_per_launch, main_fused)
-        ev1.record()
-    else:
-        # nothing between the launches and the collective waits for the host: the step kernels, the pack kernel and the gather are
-        # enqueued back to back on the stream; the launches' duration is read from two stream events after the closing barrier
-        ev0.record()
-        rollout(args.steps, False, args.turns_per_launch, main_fused)
-        ev1.record()
-        gathered = gather(env.packed_episode_results(out=gather.buffer, counts=win_counts_dev))     # one pack kernel (rows + their win counts) + one gather of 16 B per env to rank 0
-        summed_counts = win_counts_dev if args.backend == "nccl" else win_counts_dev.cpu()
-        dist.all_reduce(summed_counts)        # 4 integers per rank: the payload of the self-check below AND the closing barrier of the timed region
-        ev2.record()
-        torch.cuda.synchronize(device)
-    if not dist_on:
+    regions = []          # per repeat: [wall seconds, summed stream ms of the step launches, collective ms or None]
+    for rep in range(repeats):
+        # ---- timed region: exactly K steps; with more than one rank the path's one collective (the gather of episode results) is
+        # inside it (a single rank has nothing to exchange: its results are already where rank 0 reads them)
         barrier()
-    dt_local = time.perf_counter() - t0
-    collective_ms = None
-    if dist_on or args.timing == "torch":
-        kernel_ms_sum = ev0.elapsed_time(ev1)       # HIP events on the stream the step kernels run on (torch's current stream)
-    if dist_on:
-        collective_ms = ev1.elapsed_time(ev2)
+        t0 = time.perf_counter()
+        if not dist_on and args.timing == "native":
+            # HIP events around the step-kernel launches, recorded by the native driver on the stream it launches on and read after the last one
+            k_ms = rollout(args.steps, True, args.turns_per_launch, main_fused)
+            barrier()
+        elif not dist_on:
+            # the launches are only ENQUEUED (no event read-out, no synchronisation inside the call); their duration is taken from two stream events (created and
+            # recorded once before the region: torch creates an event at its first record()) after the closing bracket, whose torch.cuda.synchronize() is then
+            # the one host wait of the timed region
+            evs[rep][0].record()
+            rollout(args.steps, False, args.turns_per_launch, main_fused)
+            evs[rep][1].record()
+            barrier()
+        else:
+            # N > 1: step launches, ONE pack kernel and ONE collective -- the gather of 16 B per env to rank 0 -- enqueued back to back on the stream, nothing
+            # in between waits for the host.  The gather IS the closing barrier where it matters: rank 0 cannot complete it before every rank has
+            # finished its steps and packed its rows, and the job's time is the MAX over ranks (exchanged after the region), i.e. rank 0's.  The
+            # other ranks leave when their rows are on the wire.  (Round 4 closed the region with an additional all-reduce of win counts: a second
+            # RCCL launch of 25-30 us for a self-check that is now made after the region.)
+            evs[rep][0].record()
+            rollout(args.steps, False, args.turns_per_launch, main_fused)
+            evs[rep][1].record()
+            gathered = gather(env.packed_episode_results(out=gather.buffer))
+            evs[rep][2].record()
+            torch.cuda.synchronize(device)
+        regions.append([time.perf_counter() - t0, None, None])
+        if not use_events:
+            regions[-1][1] = k_ms
+    if use_events:
+        for rep in range(repeats):
+            regions[rep][1] = evs[rep][0].elapsed_time(evs[rep][1])      # HIP events on the stream the step kernels run on (torch's current stream)
+            if dist_on:
+                regions[rep][2] = evs[rep][1].elapsed_time(evs[rep][2])
     if env.check_fault():                           # (never expected: a chunk hand-over fault of a launch plan; raises)
         raise SystemExit("fault")
-    played += args.steps
-    dt = dt_local
+    played += args.steps * repeats
     per_rank = None
     if dist_on:
-        mine = torch.tensor([dt_local, kernel_ms_sum / args.steps, collective_ms * 1e3], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        # per-rank times of every repeat, exchanged AFTER the timed regions; a region's time is the max over ranks, the line's the median region
+        mine = torch.tensor([[r[0], r[1] / args.steps, r[2] * 1e3] for r in regions], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "seconds": float(t[0]), "env_steps_per_s": n_local * args.steps / float(t[0]), "kernel_ms_per_step": float(t[1]), "collective_us": float(t[2])}
-                    for r, t in enumerate(allr)]
-        dt = max(p["seconds"] for p in per_rank)
+        allr = torch.stack(allr).cpu()                                   # [world, repeats, 3]
+        region_s = allr[:, :, 0].max(dim=0).values.tolist()
+    else:
+        region_s = [r[0] for r in regions]
+    order = sorted(range(repeats), key=lambda i: region_s[i])
+    med = order[(repeats - 1) // 2]                                      # the median region (the lower one of the two middle ones for an even count)
+    dt = region_s[med]
+    kernel_ms_sum = regions[med][1]
+    collective_ms = regions[med][2]
+    if dist_on:
+        per_rank = [{"rank": r, "seconds": float(allr[r, med, 0]), "env_steps_per_s": n_local * args.steps / float(allr[r, med, 0]), "kernel_ms_per_step": float(allr[r, med, 1]),
+                     "collective_us": float(allr[r, med, 2])} for r in range(world)]
+    timing = {"repeats": repeats, "reported": "median region", "region_ms": [x * 1e3 for x in region_s], "min_ms_per_step": min(region_s) / args.steps * 1e3,
+              "max_ms_per_step": max(region_s) / args.steps * 1e3, "min_value": total * args.steps / max(region_s), "max_value": total * args.steps / min(region_s),
+              "rule": "R = 9 when K x the settle launches' ms per step < 50 ms, else 1 (--repeats N forces N); every region = exactly K steps between barrier + synchronize brackets"}
     step_kernel_ms = kernel_ms_sum / args.steps
     st = env.episode_stats()
     if not dist_on:
         gathered = gather(env.packed_episode_results())
-    final_state = env.get_state() if (world == 1 and not args.no_cpu_baseline and args.workload == "random" and played <= 2000) else None
+    final_state = env.get_state() if (world == 1 and not args.no_cpu_baseline and args.workload == "random" and played <= 6000) else None
 
-    # ---- N > 1: what the collective carried.  Every rank counts the winners of its own rows on its device; the sum over ranks (one
-    # all-reduce of 4 integers, outside the timed region) must equal what rank 0 counts in the gathered rows.
-    # (the all-reduce itself closed the timed region: its result is already here)
+    # ---- N > 1: what the collective carried.  Every rank counts the winners of its own rows on its device (the pack kernel's counted form, on the
+    # rows the last timed gather sent: nothing has been played since); the sum over ranks -- one all-reduce of 4 integers, OUTSIDE the timed region --
+    # must equal what rank 0 counts in the gathered rows.
     dist_check = None
     if dist_on:
+        env.packed_episode_results(counts=win_counts_dev)
+        summed_counts = win_counts_dev if args.backend == "nccl" else win_counts_dev.cpu()
+        dist.all_reduce(summed_counts)
         dist_check = {"wins_p0_p1_tie_unfinished_sum_over_ranks": [int(x) for x in summed_counts.tolist()]}
-
 
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
     # reference's own observation dtype (float64)
@@ -549,7 +578,7 @@ def main():
                                           "what": "PipelinedVecEnv.rollout_vs_free: per part and turn evg_random_actions_seat + evg_step_vs_policy(opponent `%s` inside the step kernel)" % args.opponent}
             pipe.close()
         if args.obs_dtype != "float64":
-            env64, rollout64 = make_env("float64")
+            env64, rollout64, _ = make_env("float64")
             rollout64(8, True, args.turns_per_launch, main_fused)
             barrier()
             t1 = time.perf_counter()
@@ -603,36 +632,57 @@ def main():
                                         "times the env-steps of the timed launches",
                      "survey_8d_bytes_per_env_step": SURVEY_ALGO_BYTES_PER_ENV_STEP,
                      "survey_8d_rate_GBps": SURVEY_ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9,
-                     "survey_8d_note": "SURVEY 8(d)'s accounting (full state read + write every turn) is NOT what this kernel moves; it is reported "
-                                       "only as survey_8d_rate_GBps and never as the roofline numerator"})
+                     "survey_8d_frac": SURVEY_ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "survey_8d_note": "SURVEY 8(d)'s byte model (the whole 1 780-byte state read + written every turn: 4 530 B per env-step) priced at this kernel time: ABOVE 1, "
+                                       "i.e. the model is not applicable to this design -- the persistent form keeps group / node / stamp words on chip for the launch and "
+                                       "touches only the float64 health rows combat hits; the game work itself is checked against the oracle (cpu_baseline.same_games_as_gpu). "
+                                       "Never the roofline numerator"})
         if roof.get("bytes_per_env_step"):
             roof["ratio_survey_8d_to_measured"] = SURVEY_ALGO_BYTES_PER_ENV_STEP / roof["bytes_per_env_step"]
         if pmc and roof["bytes_per_env_step"] < 0.5 * mand:
             roof["note"] = ("the counters see fewer bytes than the kernel writes: the working set of this batch (%.0f MB) stays in L2 / Infinity Cache, the launch is "
                             "latency- and issue-bound and `frac` says nothing about it" % (n_local * (1773 + 4 * 210 + 112) / 1e6))
-        # does "hbm" mean DRAM?  FETCH_SIZE / WRITE_SIZE count L2 <-> fabric requests, Infinity-Cache (256 MiB) hits included, and the working set
-        # of 65 536 envs (~180 MB) fits that cache.  Two passes at 262 144 envs settle it: (a) the product's launch -- whole rounds of resident
-        # workgroups one after the other, each round's working set again ~180 MB -- and (b) the chunked form forced over the whole batch
-        # (diagnostic library), which cycles through all 720 MB every few chunks, i.e. really lives beyond the cache.
+        # What the bytes are.  FETCH_SIZE / WRITE_SIZE count requests between the L2s and the fabric, Infinity-Cache (256 MiB) hits included (MI355X_MICROARCH.md, "HBM"),
+        # and a persistent launch works through its batch in rounds of resident workgroups (65 536 envs on a whole MI355X) whose working set fits that cache:
+        # the bound this object prices is then the FABRIC (L2 <-> Infinity Cache / HBM), not DRAM, and `bound` says so.
+        obs_b = {"float32": 4, "float64": 8, "int16": 2}[args.obs_dtype] * 210
+        round_ws = min(n_local, 65536) * (1773 + obs_b + 112 + 32)
+        if pmc and round_ws <= (256 << 20):
+            roof["bound"] = "fabric"
+            roof["bound_contract"] = "hbm"
+            roof["bound_is"] = ("fabric: requests between the L2s and the Infinity Cache / HBM.  The working set of a round of resident workgroups (%.0f MB) is inside the 256 MiB "
+                                "Infinity Cache, so these bytes are NOT all DRAM traffic; the counters cannot separate cache hits.  `peak` is the HBM3E figure the contract asks "
+                                "for (8 TB/s); `hbm_proper_frac` is the same kernel made to leave the cache" % (round_ws / 1e6))
+        # ... and the same kernel when its launch does leave the cache (one number, one source):
+        #   product_cycled  libevg.so itself, a plan it really launches: 131 071 envs with evg_config.cache_mib raised to 1 024, so that the plan is ONE chunked launch that
+        #                   cycles through all 359 MB of the batch every 25-turn chunk (with the default budget the library refuses such a plan BY DESIGN: plan_step keeps
+        #                   every launch's working set inside the cache -- whole rounds are cache blocking -- which is why no default product plan is HBM-bound)
+        #   cycled          the diagnostic library's chunked form forced over 262 144 envs (723 MB), the cross-check of rounds 3 and 4
         big = committed_counters("pmc_traffic", 262144, args.workload, args.obs_dtype)
         cyc = committed_counters("pmc_traffic", 262144, args.workload, args.obs_dtype, variant="cycled")
-        if pmc and n_local == 65536 and (big or cyc):
-            bm = {"envs": 262144, "working_set_MB": round(262144 * (1773 + 4 * 210 + 112 + 32) / 1e6), "infinity_cache_MB": 268}
+        prod = committed_counters("pmc_traffic", 131071, args.workload, args.obs_dtype, variant="product_cycled")
+        if pmc and n_local == 65536 and (big or cyc or prod):
+            bm = {"infinity_cache_MB": 268}
             def cmp_form(d, k):
                 fb, fs = d["forms"][k], pmc["forms"][k]
-                return {"bytes_per_env_step": fb["bytes_per_env_step_steady"], "bytes_per_env_step_at_65536": fs["bytes_per_env_step_steady"],
-                        "ns_per_env_step": fb["kernel_us_per_turn"] * 1e3 / 262144, "ns_per_env_step_at_65536": fs["kernel_us_per_turn"] * 1e3 / 65536,
+                return {"envs": d["envs"], "working_set_MB": round(d["envs"] * (1773 + obs_b + 112 + 32) / 1e6),
+                        "bytes_per_env_step": fb["bytes_per_env_step_steady"], "bytes_per_env_step_at_65536": fs["bytes_per_env_step_steady"],
+                        "ns_per_env_step": fb["kernel_us_per_turn"] * 1e3 / d["envs"], "ns_per_env_step_at_65536": fs["kernel_us_per_turn"] * 1e3 / 65536,
                         "traffic_TBps": fb["traffic_TBps"], "frac_of_8TBps": fb["frac_of_8TBps"], "source": d["_file"]}
             if big:
                 bm["whole_rounds_one_after_the_other"] = {k: cmp_form(big, k) for k in ("persistent", "one_launch_per_turn") if k in big["forms"] and k in pmc["forms"]}
             if cyc and "persistent" in cyc["forms"]:
-                c = cmp_form(cyc, "persistent")
-                bm["whole_batch_cycled_every_few_chunks"] = c
-                bm["hbm_frac_beyond_the_infinity_cache"] = c["frac_of_8TBps"]
-                bm["conclusion"] = ("the bytes are the same, the rate is not: cycled through a working set the Infinity Cache cannot hold the persistent kernel sustains "
-                                    "%.2f TB/s = %.2f of the HBM peak; the %.2f at 65 536 envs (and in whole rounds at any batch size) is the rate of the L2 <-> Infinity-Cache/HBM "
-                                    "fabric with the round's working set cache-resident" % (c["traffic_TBps"], c["frac_of_8TBps"], pmc["forms"]["persistent"]["frac_of_8TBps"]))
-                roof["bound_is"] = "fabric: L2 <-> Infinity Cache / HBM (working set of a round of resident workgroups ~180 MB < 256 MiB); HBM proper: beyond_mall.hbm_frac_beyond_the_infinity_cache"
+                bm["diag_library_chunked_over_262144_envs"] = cmp_form(cyc, "persistent")
+            if prod and "persistent" in prod["forms"]:
+                bm["product_library_chunked_over_131071_envs_cache_mib_1024"] = cmp_form(prod, "persistent")
+            hp = bm.get("product_library_chunked_over_131071_envs_cache_mib_1024") or bm.get("diag_library_chunked_over_262144_envs")
+            if hp:
+                roof["hbm_proper_frac"] = hp["frac_of_8TBps"]
+                roof["hbm_proper_source"] = hp["source"]
+                roof["hbm_proper_is"] = ("the persistent kernel in a launch that cycles through a working set the Infinity Cache cannot hold (%d envs, %d MB, every env revisited once per "
+                                         "25-turn chunk): the same instruction stream and the same bytes per env-step (%.0f) at %.3f instead of %.3f ns per env-step = %.2f TB/s = %.2f of "
+                                         "the HBM peak" % (hp["envs"], hp["working_set_MB"], hp["bytes_per_env_step"], hp["ns_per_env_step"], hp["ns_per_env_step_at_65536"],
+                                                           hp["traffic_TBps"], hp["frac_of_8TBps"]))
             roof["beyond_mall"] = bm
         for leg, key in ((per_turn_launch, "one_launch_per_turn"), (caller_leg, "caller_actions_per_turn"), (learner_leg, "learner_vs_bot_per_turn")):
             if leg is not None:
@@ -665,6 +715,7 @@ def main():
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
                        "gathered_wins_all_ranks": list(evg.ResultGather.win_counts(gathered)) if gathered is not None else None},
             "roofline": roof,
+            "timing": timing,
         }
         if valu:
             out["roofline_valu_issue"] = valu
@@ -678,11 +729,12 @@ def main():
             except Exception as ex:                       # reporting only
                 ver = "unavailable (%s)" % type(ex).__name__
             out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
-                                  "collective": "one pack kernel (rows + their win counts) + torch.distributed.%s of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather) + all_reduce of the 4 win counts (= the closing barrier), inside the timed region" % gather.collective,
+                                  "collective": "one pack kernel + ONE torch.distributed.%s of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather), inside the timed region; the win-count self-check (all_reduce of 4 integers) runs after it" % gather.collective,
                                   "collective_us": max(p["collective_us"] for p in per_rank),
-                                  "collective_us_is": "stream time from the end of the last step launch to the end of the all-reduce (pack kernel, gather, all-reduce), slowest rank",
+                                  "collective_us_is": "stream time from the end of the last step launch to the end of the gather (pack kernel + gather), slowest rank, median region",
                                   "step_launches_us": max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3,
-                                  "closing_bracket": "all_reduce(win counts of every rank's own rows) + torch.cuda.synchronize() -- the barrier of the contract carrying the self-check's payload",
+                                  "closing_bracket": "completion of the gather (rank 0 receives every rank's rows: it cannot end before the slowest rank's steps) + torch.cuda.synchronize(); per-rank times exchanged afterwards, max over ranks",
+                                  "step_share_of_region": max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3 / (max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3 + max(p["collective_us"] for p in per_rank)),
                                   "expected": expected_if_wire_free(world, args.steps),
                                   "collective_calls": gather.calls, "gathered_rows": int(gathered.shape[0]), "gathered_rows_with_a_finished_episode_per_rank": gather.rows_per_rank(gathered),
                                   "rows_expected_per_rank": gather.counts,

@@ -28,6 +28,26 @@ EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
 
+def kernel_source_files():
+    """The files the product's device code is compiled from: every header and include of csrc/ (kernels, phases, RNG) plus the public header;
+    NOT the host side (evg_abi.hip).  Sorted by name, so the hash does not depend on directory order."""
+    import glob
+    csrc = os.path.join(HERE, "csrc")
+    files = sorted(f for pat in ("*.h", "*.inc", "evg_kernels.hip") for f in glob.glob(os.path.join(csrc, pat)))
+    return files + [os.path.join(os.path.dirname(HERE), "include", "evg.h")]
+
+
+def kernel_source_hash():
+    """Identifies the kernel sources a libevg.so was built from: the counter passes committed under profiles/ carry it, and bench.py uses
+    only figures whose hash equals the one of the tree it runs in (the ONE definition: bench.py and tools/_prof.py call this)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in kernel_source_files():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 class EvgTables(C.Structure):
     _fields_ = [
         ("node_dist", (C.c_int32 * 12) * 12), ("node_control_points", C.c_int32 * 12),

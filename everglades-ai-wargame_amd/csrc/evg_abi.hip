@@ -58,6 +58,15 @@ struct DeviceGuard {
     DeviceGuard guard_((h)->cfg.device_id);                                                                   \
     if (guard_.err != hipSuccess) return fail(EVG_ERR_HIP, "selecting device %d failed: %s", (h)->cfg.device_id, hipGetErrorString(guard_.err))
 
+// Device buffers of the caller: the kernels read and write them with 8- and 16-byte vector accesses (observation rows 16 bytes per lane, order rows int2 /
+// uint4, rewards float2, scores int2), so every one of them must be 16-byte aligned (include/evg.h, "Conventions"; any hipMalloc / torch allocation is).
+// NULL is "not given" and passes.
+bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+#define EVG_NEED_ALIGNED16(p)                                                                                 \
+    do {                                                                                                      \
+        if (misaligned16(p)) return fail(EVG_ERR_INVALID, "%s must be 16-byte aligned (got %p)", #p, (const void*)(p)); \
+    } while (0)
+
 // numpy pairwise order for the cached int(avg health) (server.py:481,491); state import only
 double host_np_sum(const double* h, int n) {
     double s = ((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7]));
@@ -133,16 +142,19 @@ static int check_fault(evg_handle* h, uint32_t* word_out = nullptr) {
         if (!fault) fault = 0x80000000u;        // the mirror says so, the word does not: report it all the same
     }
     if (word_out) *word_out = fault;
-    if (fault) return fail(EVG_ERR_FAULT, "a chunked rollout launch failed to hand a set of envs on (fault word %u: 1 = a workgroup gave up waiting for a predecessor chunk, 2 = a workgroup "
-                                          "ran on an XCD the create-time probe did not see, 4 = a queue of a chunked launch was not drained): the state and the results of this handle "
-                                          "are not valid; destroy it", fault);
+    if (fault)
+        return fail(EVG_ERR_FAULT,
+                    "a chunked rollout launch failed to hand a set of envs on (fault word %u: 1 = a workgroup gave up waiting for a predecessor chunk, "
+                    "2 = a workgroup ran on an XCD the create-time probe did not see, 4 = a queue of a chunked launch was not drained): the state and "
+                    "the results of this handle are not valid; destroy it",
+                    fault);
     return EVG_OK;
 }
 
 static bool same_launch(const StepIO& a, const StepIO& b) {
-    bool same = a.actions == b.actions && a.obs == b.obs && a.reward == b.reward && a.done == b.done && a.winner == b.winner && a.scores == b.scores && a.status == b.status &&
-                a.observe_only == b.observe_only && a.gen_actions == b.gen_actions && a.policy0 == b.policy0 && a.policy1 == b.policy1 && a.actions_out == b.actions_out &&
-                a.turns == b.turns && a.seat == b.seat && a.actions_both == b.actions_both;
+    bool same = a.actions == b.actions && a.obs == b.obs && a.reward == b.reward && a.done == b.done && a.winner == b.winner && a.scores == b.scores &&
+                a.status == b.status && a.observe_only == b.observe_only && a.gen_actions == b.gen_actions && a.policy0 == b.policy0 &&
+                a.policy1 == b.policy1 && a.actions_out == b.actions_out && a.turns == b.turns && a.seat == b.seat && a.actions_both == b.actions_both;
 #ifdef EVG_DIAG
     same = same && a.lanes_per_wave == b.lanes_per_wave && a.ablate == b.ablate && a.stamps == b.stamps;
 #endif
@@ -284,13 +296,16 @@ static void fill_lds_tables(DevTables* D) {
     memset(&L, 0, sizeof(L));
     for (int n = 0; n < 12; ++n) {
         L.adj[n] = D->adj_row[n];
-        L.cp[n] = D->control_points[n]; L.ts[n] = D->team_start[n]; L.res[n] = ((D->resource[n] & EVG_RES_DEFENSE) ? 1 : 0) | ((D->resource[n] & EVG_RES_OBSERVE) ? 1 << 16 : 0);
+        L.cp[n] = D->control_points[n]; L.ts[n] = D->team_start[n];
+        L.res[n] = ((D->resource[n] & EVG_RES_DEFENSE) ? 1 : 0) | ((D->resource[n] & EVG_RES_OBSERVE) ? 1 << 16 : 0);
         L.init_node[n] = D->init_node[n];
     }
     for (int i = 0; i < 48; ++i) { L.den[i] = (&D->den_tab[0][0])[i]; L.rcp[i] = (&D->rcp_tab[0][0])[i]; }
     for (int i = 0; i < 24; ++i) L.init_grp[i] = D->init_grp[i];
     L.nib[0] = D->p1map_nib;
-    for (int p = 0; p < NP; ++p) { L.nib[1 + p] = D->speed_nib[p]; L.nib[3 + p] = D->control_nib[p]; L.nib[5 + p] = D->cost_nib[p]; L.nib[7 + p] = D->type_nib[p]; }
+    for (int p = 0; p < NP; ++p) {
+        L.nib[1 + p] = D->speed_nib[p]; L.nib[3 + p] = D->control_nib[p]; L.nib[5 + p] = D->cost_nib[p]; L.nib[7 + p] = D->type_nib[p];
+    }
     L.nib[10] = D->p1inv_nib;
     L.nib[11] = D->maxnbr_nib;
     L.nib[12] = D->tar_to_1;
@@ -478,14 +493,19 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (!rc) rc = dev_alloc(h, &S.agent_cycle, 2 * N);
     if (!rc) rc = dev_alloc(h, &S.agent_swarm, 2 * N);
     if (!rc) rc = dev_alloc(h, &S.agent_dfs, 2 * N);
-    if (!rc) rc = dev_alloc(h, &S.queue, 1024 + (N + 31) / 32 + 1);      // 16 queue counters on lines of their own (the create-time XCD probe borrows the 1 024 words) ...
+    // 16 queue counters on lines of their own (the create-time XCD probe borrows the 1 024 words) ...
+    if (!rc) rc = dev_alloc(h, &S.queue, 1024 + (N + 31) / 32 + 1);
     if (!rc) S.progress = S.queue + 1024;                                // ... and the per-set progress flags behind them: one memset zeroes both
     if (!rc) rc = dev_alloc(h, &S.fault, 1);
     if (!rc) {        // host-mapped mirror of "the fault word is not zero" (check_fault)
         void* hp = nullptr;
         void* dp = nullptr;
         hipError_t he = hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped);
-        if (he == hipSuccess) { *reinterpret_cast<uint32_t*>(hp) = 0u; h->fault_seen_host = reinterpret_cast<uint32_t*>(hp); he = hipHostGetDevicePointer(&dp, hp, 0); }
+        if (he == hipSuccess) {
+            *reinterpret_cast<uint32_t*>(hp) = 0u;
+            h->fault_seen_host = reinterpret_cast<uint32_t*>(hp);
+            he = hipHostGetDevicePointer(&dp, hp, 0);
+        }
         if (he != hipSuccess) rc = fail(EVG_ERR_ALLOC, "mapped host word: %s", hipGetErrorString(he));
         S.fault_seen = reinterpret_cast<uint32_t*>(dp);
     }
@@ -510,8 +530,8 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
             const hipError_t ae = hipPointerGetAttributes(&at, q);
             if (ae != hipSuccess || at.type != hipMemoryTypeDevice || at.isManaged) {
                 evg_destroy(h);
-                return fail(EVG_ERR_HIP, "the state arrays must be plain device memory (hipMalloc); got type %d managed %d (%s)", ae == hipSuccess ? (int)at.type : -1,
-                            ae == hipSuccess ? (int)at.isManaged : -1, hipGetErrorString(ae));
+                return fail(EVG_ERR_HIP, "the state arrays must be plain device memory (hipMalloc); got type %d managed %d (%s)",
+                            ae == hipSuccess ? (int)at.type : -1, ae == hipSuccess ? (int)at.isManaged : -1, hipGetErrorString(ae));
             }
         }
     }
@@ -574,6 +594,7 @@ int evg_state_bytes_per_env(const evg_handle* h) {
 
 int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    EVG_NEED_ALIGNED16(obs_out);
     EVG_ON_DEVICE(h);
     const int rc = launch_reset(h->S, mask, obs_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "reset launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -584,6 +605,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
              int32_t* scores_out, uint8_t* status_out, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
+    EVG_NEED_ALIGNED16(actions); EVG_NEED_ALIGNED16(obs_out); EVG_NEED_ALIGNED16(reward_out); EVG_NEED_ALIGNED16(scores_out);
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, 0, 0, nullptr);
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
@@ -593,6 +615,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
 
 int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
+    EVG_NEED_ALIGNED16(obs_out);
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, nullptr, obs_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr);
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
@@ -605,7 +628,7 @@ int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int acti
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !obs_seat_out || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, obs_seat_out, reward_out and done_out are required");
     if (seat < 0 || seat > 1 || opponent_policy < 0 || opponent_policy >= EVG_POLICY_COUNT) return fail(EVG_ERR_INVALID, "seat / opponent_policy out of range");
-    if ((reinterpret_cast<uintptr_t>(obs_seat_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "obs_seat_out must be 16-byte aligned");
+    EVG_NEED_ALIGNED16(obs_seat_out); EVG_NEED_ALIGNED16(actions); EVG_NEED_ALIGNED16(reward_out); EVG_NEED_ALIGNED16(scores_out);
     if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_step_vs_policy: keyed-Philox handles only (the stock-entropy mode has no fused bots)");
     EVG_ON_DEVICE(h);
     StepIO io = make_io(h, actions, obs_seat_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 2, opponent_policy, opponent_policy, nullptr);
@@ -617,7 +640,7 @@ int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int acti
 
 int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream) {
     if (!h || !obs_seat_out || seat < 0 || seat > 1) return fail(EVG_ERR_INVALID, "bad argument");
-    if ((reinterpret_cast<uintptr_t>(obs_seat_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "obs_seat_out must be 16-byte aligned");
+    EVG_NEED_ALIGNED16(obs_seat_out);
     if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_observe_seat: keyed-Philox handles only");
     EVG_ON_DEVICE(h);
     StepIO io = make_io(h, nullptr, obs_seat_out, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr);
@@ -629,6 +652,7 @@ int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream) 
 
 int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
     if (!h || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
+    EVG_NEED_ALIGNED16(actions_out);
     EVG_ON_DEVICE(h);
     const int rc = launch_random_actions(h->S, actions_out, -1, stream);
     if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -637,7 +661,7 @@ int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
 
 int evg_random_actions_seat(evg_handle* h, int seat, int32_t* actions_seat_out, void* stream) {
     if (!h || !actions_seat_out || seat < 0 || seat > 1) return fail(EVG_ERR_INVALID, "bad argument");
-    if ((reinterpret_cast<uintptr_t>(actions_seat_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "actions_seat_out must be 16-byte aligned");
+    EVG_NEED_ALIGNED16(actions_seat_out);
     EVG_ON_DEVICE(h);
     const int rc = launch_random_actions(h->S, actions_seat_out, seat, stream);
     if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -647,6 +671,7 @@ int evg_random_actions_seat(evg_handle* h, int seat, int32_t* actions_seat_out, 
 int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream) {
     if (!h || !obs || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
     if (policy < 0 || policy >= EVG_POLICY_COUNT || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "policy/player out of range");
+    EVG_NEED_ALIGNED16(obs); EVG_NEED_ALIGNED16(actions_out);
     EVG_ON_DEVICE(h);
     const int rc = launch_scripted_actions(h->S, policy, player, obs, actions_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "scripted_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -671,7 +696,7 @@ int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream) {
 
 int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream) {
     if (!h || !obs || !features_out || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
-    if ((reinterpret_cast<uintptr_t>(features_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "features_out must be 16-byte aligned");
+    EVG_NEED_ALIGNED16(features_out); EVG_NEED_ALIGNED16(obs);
     EVG_ON_DEVICE(h);
     const int rc = launch_smart_state(h->S, player, obs, 0, features_out, nullptr, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -680,7 +705,7 @@ int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_
 
 int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_out, void* stream) {
     if (!h || !obs_seat || !features_out) return fail(EVG_ERR_INVALID, "bad argument");
-    if ((reinterpret_cast<uintptr_t>(features_out) & 15u) != 0) return fail(EVG_ERR_INVALID, "features_out must be 16-byte aligned");
+    EVG_NEED_ALIGNED16(features_out); EVG_NEED_ALIGNED16(obs_seat);
     EVG_ON_DEVICE(h);
     const int rc = launch_smart_state(h->S, 0, obs_seat, 1, features_out, nullptr, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -689,8 +714,8 @@ int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_ou
 
 int evg_smart_state_compact(evg_handle* h, int player, const void* obs, float* shared_out, float* swarm_out, void* stream) {
     if (!h || !obs || !shared_out || !swarm_out || player < -1 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
-    if ((reinterpret_cast<uintptr_t>(shared_out) & 7u) != 0 || (reinterpret_cast<uintptr_t>(swarm_out) & 15u) != 0)
-        return fail(EVG_ERR_INVALID, "shared_out must be 8-byte, swarm_out 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(shared_out) & 7u) != 0) return fail(EVG_ERR_INVALID, "shared_out must be 8-byte aligned");
+    EVG_NEED_ALIGNED16(swarm_out); EVG_NEED_ALIGNED16(obs);
     EVG_ON_DEVICE(h);
     const int rc = launch_smart_state(h->S, player < 0 ? 0 : player, obs, player < 0 ? 1 : 0, shared_out, swarm_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -739,6 +764,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
     if (prepare_only) steps = -steps;
     if (steps < 1 || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, reward_out, done_out required");
     if (!actions_buf && !fused) return fail(EVG_ERR_INVALID, "rollout: actions_buf is required unless the step kernel produces the orders itself (fused >= 1)");
+    EVG_NEED_ALIGNED16(actions_buf); EVG_NEED_ALIGNED16(obs_out); EVG_NEED_ALIGNED16(reward_out); EVG_NEED_ALIGNED16(scores_out);
     EVG_ON_DEVICE(h);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipStream_t s_ = s;
@@ -789,7 +815,8 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
         HIP_TRY(hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    const StepIO io = make_io(h, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? gen_mode : 0, policy0, policy1, actions_buf);
+    const StepIO io = make_io(h, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, fused ? gen_mode : 0, policy0, policy1,
+                              actions_buf);
     if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[0], s_));
     for (int i = 0; i < steps; ++i) {
         int rc = 0;
@@ -816,12 +843,14 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
     return EVG_OK;
 }
 
-int evg_rollout_vs_policy(evg_handle* h, int steps, int seat, int opponent_policy, int32_t* actions_seat_buf, void* obs_seat_out, float* reward_out, uint8_t* done_out,
+int evg_rollout_vs_policy(evg_handle* h, int steps, int seat, int opponent_policy, int32_t* actions_seat_buf, void* obs_seat_out, float* reward_out,
+                          uint8_t* done_out,
                           int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
-    if (steps < 1 || !actions_seat_buf || !obs_seat_out || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout_vs_policy: steps >= 1, actions_seat_buf, obs_seat_out, reward_out, done_out required");
+    if (steps < 1 || !actions_seat_buf || !obs_seat_out || !reward_out || !done_out)
+        return fail(EVG_ERR_INVALID, "rollout_vs_policy: steps >= 1, actions_seat_buf, obs_seat_out, reward_out, done_out required");
     if (seat < 0 || seat > 1 || opponent_policy < 0 || opponent_policy >= EVG_POLICY_COUNT) return fail(EVG_ERR_INVALID, "seat / opponent_policy out of range");
-    if (((reinterpret_cast<uintptr_t>(obs_seat_out) | reinterpret_cast<uintptr_t>(actions_seat_buf)) & 15u) != 0) return fail(EVG_ERR_INVALID, "obs_seat_out and actions_seat_buf must be 16-byte aligned");
+    EVG_NEED_ALIGNED16(obs_seat_out); EVG_NEED_ALIGNED16(actions_seat_buf); EVG_NEED_ALIGNED16(reward_out); EVG_NEED_ALIGNED16(scores_out);
     if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_rollout_vs_policy: keyed-Philox handles only");
     EVG_ON_DEVICE(h);
     hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);
@@ -830,7 +859,8 @@ int evg_rollout_vs_policy(evg_handle* h, int steps, int seat, int opponent_polic
         HIP_TRY(hipEventCreate(&ev));
         h->events.push_back(ev);
     }
-    StepIO io = make_io(h, actions_seat_buf, obs_seat_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 2, opponent_policy, opponent_policy, nullptr);
+    StepIO io = make_io(h, actions_seat_buf, obs_seat_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 2, opponent_policy, opponent_policy,
+                        nullptr);
     io.seat = seat; io.actions_both = 0;
     if (step_kernel_ms) HIP_TRY(hipEventRecord(h->events[0], s_));
     for (int i = 0; i < steps; ++i) {
@@ -1006,11 +1036,13 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
  *   ablate          bit0 orders, bit1 combat, bit2 movement, bit4 observation write-out, bit5 state store are skipped; bit6: a chunked launch never
  *                   publishes the first chunk of its first set (the fault path: its successor gives up after ~1 s and flags the handle)
  *   lanes_per_wave  0 (default: what the product library launches), 2 (experiment: persistent rollouts of a batch beyond what the device holds run the
- *                   CHUNKED form over the whole batch, i.e. with a working set larger than the Infinity Cache), 64 (the two-lanes-per-env kernel at every batch size and in both
+ *                   CHUNKED form over the whole batch, i.e. with a working set larger than the Infinity Cache), 64 (the two-lanes-per-env kernel at every batch
+ *                   size and in both
  *                   launch forms), 32 (16 envs per wavefront + 32 helper lanes) or 4 (the four-lanes-per-env kernel in both launch forms)
  *   force_ieee_div  != 0: run the step kernel's true-division branch although the table set passed the exact-quotient check */
 EVG_API int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) {
-    if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4 && lanes_per_wave != 2)) return fail(EVG_ERR_INVALID, "diag: bad argument");
+    if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4 && lanes_per_wave != 2))
+        return fail(EVG_ERR_INVALID, "diag: bad argument");
     EVG_ON_DEVICE(h);
     h->ablate = ablate;
     h->lanes = lanes_per_wave;
@@ -1052,16 +1084,29 @@ int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int bu
         if (h->lanes == 4) kname = "evg_step4_kernel";
         if (h->lanes == 64 || h->lanes == 32) kname = "evg_step_kernel";
 #endif
-        if (h->S.mt_key) snprintf(tmp, sizeof(tmp), "%sevg_step_kernel<stock MT19937>[envs %d..%d: %d wavefronts of 32 envs]", i ? " + " : "", pc.env_lo, pc.env_hi, (n + 31) / 32);
-        else if (pc.four_lane_wpe) snprintf(tmp, sizeof(tmp), "%s%s<four lanes per env, built for %d waves per SIMD>[envs %d..%d: %d wavefronts of 16 envs]", i ? " + " : "", kname, pc.four_lane_wpe, pc.env_lo, pc.env_hi, (n + epw - 1) / epw);
-        else if (pc.chunk_turns > 0) snprintf(tmp, sizeof(tmp), "%s%s<two lanes per env, persistent, chunked>[envs %d..%d: %d sets of 32 envs x %d chunks of %d turns, taken from %d per-XCD queues by %d workgroups]", i ? " + " : "", kname,
-                                              pc.env_lo, pc.env_hi, (n + epw - 1) / epw, (turns_per_launch + pc.chunk_turns - 1) / pc.chunk_turns, pc.chunk_turns, h->S.nxcd,
-                                              (n + epw - 1) / epw < h->caps.slots2 ? (n + epw - 1) / epw : h->caps.slots2);
-        else snprintf(tmp, sizeof(tmp), "%s%s<two lanes per env, %s>[envs %d..%d: %d wavefronts of 32 envs]", i ? " + " : "", kname, turns_per_launch > 1 ? "persistent" : "single-turn", pc.env_lo, pc.env_hi, (n + epw - 1) / epw);
+        const char* plus = i ? " + " : "";
+        const int nw = (n + epw - 1) / epw;          // wavefronts (sets of envs) of this piece
+        if (h->S.mt_key)
+            snprintf(tmp, sizeof(tmp), "%sevg_step_kernel<stock MT19937>[envs %d..%d: %d wavefronts of 32 envs]", plus, pc.env_lo, pc.env_hi, (n + 31) / 32);
+        else if (pc.four_lane_wpe)
+            snprintf(tmp, sizeof(tmp), "%s%s<four lanes per env, built for %d waves per SIMD>[envs %d..%d: %d wavefronts of 16 envs]", plus, kname,
+                     pc.four_lane_wpe, pc.env_lo, pc.env_hi, nw);
+        else if (pc.chunk_turns > 0)
+            snprintf(tmp, sizeof(tmp),
+                     "%s%s<two lanes per env, persistent, chunked>[envs %d..%d: %d sets of 32 envs x %d chunks of %d turns, "
+                     "taken from %d per-XCD queues by %d workgroups]",
+                     plus, kname, pc.env_lo, pc.env_hi, nw, (turns_per_launch + pc.chunk_turns - 1) / pc.chunk_turns, pc.chunk_turns, h->S.nxcd,
+                     nw < h->caps.slots2 ? nw : h->caps.slots2);
+        else
+            snprintf(tmp, sizeof(tmp), "%s%s<two lanes per env, %s>[envs %d..%d: %d wavefronts of 32 envs]", plus, kname,
+                     turns_per_launch > 1 ? "persistent" : "single-turn", pc.env_lo, pc.env_hi, nw);
         s += tmp;
     }
-    snprintf(tmp, sizeof(tmp), " | device: %d CUs, resident wavefronts two-lane %d, four-lane %d / %d, %d XCDs, Infinity-Cache budget of a launch that cycles through its envs %lld MiB (%lld B per env)", h->caps.cus,
-             h->caps.slots2, h->caps.slots4_w2, h->caps.slots4_w3, h->S.nxcd, (long long)(h->caps.cache_bytes >> 20), rollout_bytes_per_env(io, h->cfg.obs_dtype));
+    snprintf(tmp, sizeof(tmp),
+             " | device: %d CUs, resident wavefronts two-lane %d, four-lane %d / %d, %d XCDs, Infinity-Cache budget of a launch that cycles through its envs "
+             "%lld MiB (%lld B per env)",
+             h->caps.cus, h->caps.slots2, h->caps.slots4_w2, h->caps.slots4_w3, h->S.nxcd, (long long)(h->caps.cache_bytes >> 20),
+             rollout_bytes_per_env(io, h->cfg.obs_dtype));
     s += tmp;
     snprintf(buf, (size_t)buflen, "%s", s.c_str());
     return p.n;
@@ -1069,7 +1114,7 @@ int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int bu
 
 int evg_pack_episode_results(evg_handle* h, float* out, void* stream) {
     if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
-    if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0) return fail(EVG_ERR_INVALID, "out must be 16-byte aligned");
+    EVG_NEED_ALIGNED16(out);
     EVG_ON_DEVICE(h);
     const int rc = launch_pack_results(h->S, out, nullptr, stream);
     if (rc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1078,7 +1123,8 @@ int evg_pack_episode_results(evg_handle* h, float* out, void* stream) {
 
 int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t* counts_out, void* stream) {
     if (!h || !out || !counts_out) return fail(EVG_ERR_INVALID, "null argument");
-    if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0 || (reinterpret_cast<uintptr_t>(counts_out) & 7u) != 0) return fail(EVG_ERR_INVALID, "out must be 16-byte, counts_out 8-byte aligned");
+    EVG_NEED_ALIGNED16(out);
+    if ((reinterpret_cast<uintptr_t>(counts_out) & 7u) != 0) return fail(EVG_ERR_INVALID, "counts_out must be 8-byte aligned");
     EVG_ON_DEVICE(h);
     const int rc = launch_pack_results(h->S, out, reinterpret_cast<long long*>(counts_out), stream);
     if (rc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)rc));

@@ -103,9 +103,10 @@ struct DevState {
     uint32_t  seed_lo, seed_hi, env_id_base;
     const DevTables* T;
     uint32_t* progress;          // [ceil(N / 32)] chunked persistent launches: set s of 32 envs has finished chunk c of the launch <=> progress[s] == c + 1
-    uint32_t* queue;             // [1024] chunked launches: next unit of each XCD's queue, one counter per 256-byte line.  queue and progress are ONE allocation (queue
-                                 // first), zeroed by one memset on the stream before every chunked launch
-    uint32_t* fault;             // [1] bit 0: a wave gave up waiting for a predecessor chunk; bit 1: a workgroup ran on an XCD the create-time probe did not see;
+    uint32_t* queue;             // [1024] chunked launches: next unit of each XCD's queue, one counter per 256-byte line.  queue and progress are ONE
+                                 // allocation (queue first), zeroed by one memset on the stream before every chunked launch
+    uint32_t* fault;             // [1] bit 0: a wave gave up waiting for a predecessor chunk; bit 1: a workgroup ran on an XCD the create-time probe did
+                                 // not see;
                                  // bit 2: a queue of a chunked launch was not drained (evg_chunk_verify_kernel, on the stream behind every chunked launch).
                                  // Never expected; sticky; read by the pack kernel (poisoned rows) and by every host path on which results leave the handle
     uint32_t* fault_seen;        // [1] host-mapped mirror: set to 1 (plain store) together with any bit of `fault`, so that the host checks cost no device copy
@@ -130,14 +131,16 @@ struct StepIO {
     int32_t   env_lo, env_hi;    // this launch plays envs [env_lo, env_hi) of the handle (workgroup b: envs env_lo + b * envs-per-wave ...);
                                  // set by launch_step, which may split a batch into several launches (LaunchPlan)
     int32_t   flags;             // STEP_F_*: set by launch_step from the device's capacity (DeviceCaps), not from literals
-    int32_t   seat;              // SEAT instantiation (evg_step_vs_policy / evg_observe_seat): the caller's seat; its 7 rows come from `actions` ([N][7][2], or rows
-                                 // [:, seat] of [N][2][7][2] when actions_both != 0), the other seat's from policy0 / policy1 (gen_actions == 2), and obs is [N][105]
+    int32_t   seat;              // SEAT instantiation (evg_step_vs_policy / evg_observe_seat): the caller's seat; its 7 rows come from `actions` ([N][7][2],
+                                 // or rows [:, seat] of [N][2][7][2] when actions_both != 0), the other seat's from policy0 / policy1 (gen_actions == 2),
+                                 // and obs is [N][105]
     int32_t   actions_both;
     int32_t   nsets;             // > 0: CHUNKED persistent launch of the two-lane kernel (batches beyond what the device holds at once): workgroup u
                                  // plays chunk u / nsets (chunk_turns consecutive turns, the last one what is left of `turns`) of env set u % nsets
     int32_t   chunk_turns;
     int32_t   grid_slots;        // workgroups of a chunked launch (what the device holds at once)
-    uint32_t  progress_base;     // value of DevState::progress[set] that means "no chunk of this launch finished yet" (0: the flags are zeroed before every launch)
+    uint32_t  progress_base;     // value of DevState::progress[set] that means "no chunk of this launch finished yet" (0: the flags are zeroed before
+                                 // every launch)
 #ifdef EVG_DIAG                  // diagnostic libraries only (libevg_diag.so, libevg_stamps.so)
     int32_t   lanes_per_wave;    // 64: 32 envs per wavefront; 32: 16 envs per wavefront + 32 helper lanes
     uint32_t  ablate;            // bit0 orders, bit1 combat, bit2 movement, bit4 obs write-out, bit5 state store
@@ -163,8 +166,8 @@ struct DeviceCaps {
 constexpr int kStateBytesPerEnv = 24 * 4 + 6 * 4 + 6 * 4 + 4 + 4 + 2 * NU * 8 + 2 * 4;
 
 // One launch of a plan: which kernel plays which envs.
-struct LaunchPiece { int32_t four_lane_wpe; int32_t env_lo, env_hi; int32_t chunk_turns; };   // four_lane_wpe: 0 = two-lane kernel, 2 / 3 = four-lane kernel built for that
-                                                                                              // many waves per SIMD; chunk_turns > 0: chunked dispatch (two-lane kernel only)
+// four_lane_wpe: 0 = two-lane kernel, 2 / 3 = four-lane kernel built for that many waves per SIMD; chunk_turns > 0: chunked dispatch (two-lane kernel only)
+struct LaunchPiece { int32_t four_lane_wpe; int32_t env_lo, env_hi; int32_t chunk_turns; };
 struct LaunchPlan { int32_t n; LaunchPiece piece[2]; };
 
 // launchers (evg_kernels.hip)
@@ -180,7 +183,8 @@ int launch_scripted_actions(const DevState& S, int policy, int player, const voi
 int launch_scripted_reset(const DevState& S, void* stream);
 int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, int8_t* sight, void* stream);
 int launch_mt_seed(const DevState& S, const uint32_t* seeds_dev, void* stream);
-int launch_smart_state(const DevState& S, int player, const void* obs, int seat_only /* obs is [N][105] */, float* out, float* out_swarm /* non-NULL: compact form, out = shared [N][34], out_swarm [N][12][13] */, int obs_dtype, void* stream);
+int launch_smart_state(const DevState& S, int player, const void* obs, int seat_only /* obs is [N][105] */, float* out,
+                       float* out_swarm /* non-NULL: compact form, out = shared [N][34], out_swarm [N][12][13] */, int obs_dtype, void* stream);
 int launch_pack_results(const DevState& S, float* out, long long* counts /* device [4] or NULL */, void* stream);
 
 }  // namespace evg

@@ -12,6 +12,10 @@
  * Conventions
  *   - plain C, no torch types; every pointer marked "device" is a HIP device pointer owned by the
  *     caller (e.g. torch.Tensor.data_ptr()); the handle owns only the persistent game state.
+ *   - ALIGNMENT: every device buffer of observations, orders, rewards, scores, features or packed results handed to the library must be
+ *     16-byte aligned (the kernels move them with 8- and 16-byte vector accesses: observation rows 16 bytes per lane, order rows as
+ *     int2 / uint4, rewards float2, scores int2).  Any hipMalloc / torch allocation is; a slice of one need not be.  Checked by every entry
+ *     point: EVG_ERR_INVALID names the pointer.  Byte arrays (done, winner, status, mask, fog planes) have no requirement.
  *   - all calls return 0 on success or a negative evg_status; evg_last_error() gives the text
  *     (thread-local).  No C++ exception crosses the ABI.
  *   - step/reset/random_actions ENQUEUE on the caller's hipStream_t (`stream`, may be NULL for the
@@ -31,8 +35,11 @@
 extern "C" {
 #endif
 
-#define EVG_ABI_VERSION 4      /* 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat,
-                                  evg_smart_state_compact, evg_check_fault + EVG_ERR_FAULT, evg_pack_episode_results_counted, evg_config.cache_mib; 3: evg_launch_plan; 2: evg_pack_episode_results, node words as u32 */
+#define EVG_ABI_VERSION 4
+/* 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat, evg_smart_state_compact,
+ *    evg_check_fault + EVG_ERR_FAULT, evg_pack_episode_results_counted, evg_config.cache_mib
+ * 3: evg_launch_plan
+ * 2: evg_pack_episode_results, node words as u32 */
 
 /* The ABI is exactly the functions declared in this header: the library is built with -fvisibility=hidden and only they are exported. */
 #define EVG_API __attribute__((visibility("default")))
@@ -356,8 +363,8 @@ EVG_API int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t*
  * every launch of the plan, and the device capacity the plan was derived from (compute units from hipDeviceProp_t, resident
  * wavefronts from the kernels' own occupancy -- no 256-CU literal; the XCDs the create-time probe saw; the memory-side cache budget a chunked launch may
  * cycle through, evg_config.cache_mib, and the bytes per env it is compared with).  The plan described is the one of a rollout that writes observations and
- * records the orders (a rollout without them has a smaller footprint and may chunk a slightly larger batch).  turns_per_launch == 1 describes evg_step.  Returns the
- * number of kernel launches per rollout launch (>= 1) or a negative evg_status. */
+ * records the orders (a rollout without them has a smaller footprint and may chunk a slightly larger batch).  turns_per_launch == 1 describes evg_step.
+ * Returns the number of kernel launches per rollout launch (>= 1) or a negative evg_status. */
 EVG_API int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen);
 
 EVG_API int evg_num_envs(const evg_handle* h);

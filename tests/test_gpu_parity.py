@@ -1172,6 +1172,29 @@ def test_abi_error_paths_on_a_device(evg):
         pk = torch.zeros((9, 4), device="cuda")
         assert lib.evg_pack_episode_results(h, None, None) == -1 and lib.evg_pack_episode_results(None, p(pk), None) == -1
         assert lib.evg_pack_episode_results(h, C.c_void_p(pk.data_ptr() + 4), None) == -1 and b"aligned" in lib.evg_last_error()
+        # alignment (include/evg.h "Conventions"): the kernels move observations, orders, rewards and scores with 8- / 16-byte vector accesses, so a
+        # misaligned device buffer is refused by every entry point that takes one -- before a launch, with the pointer named
+        off = lambda t, b=4: C.c_void_p(t.data_ptr() + b)
+        sc = torch.zeros((8, 2), dtype=torch.int32, device="cuda")
+        big_obs = torch.zeros((9, 2, 105), device="cuda")
+        big_act = torch.zeros((9, 2, 7, 2), dtype=torch.int32, device="cuda")
+
+        def refused(rc, name):
+            assert rc == -1 and b"16-byte aligned" in lib.evg_last_error() and name in lib.evg_last_error(), (rc, lib.evg_last_error())
+        refused(lib.evg_reset(h, None, off(big_obs), None), b"obs_out")
+        refused(lib.evg_observe(h, off(big_obs), None), b"obs_out")
+        refused(lib.evg_step(h, p(act), off(big_obs), p(rew), p(done), None, None, None, None), b"obs_out")
+        refused(lib.evg_step(h, off(big_act, 8), p(obs), p(rew), p(done), None, None, None, None), b"actions")
+        refused(lib.evg_step(h, p(act), p(obs), off(big_obs, 8), p(done), None, None, None, None), b"reward_out")
+        refused(lib.evg_step(h, p(act), p(obs), p(rew), p(done), None, off(sc, 8), None, None), b"scores_out")
+        refused(lib.evg_random_actions(h, off(big_act, 8), None), b"actions_out")
+        refused(lib.evg_scripted_actions(h, 1, 0, p(obs), off(big_act, 8), None), b"actions_out")
+        refused(lib.evg_rollout_random(h, 3, 1, p(act), off(big_obs), p(rew), p(done), None, None, None, None, None), b"obs_out")
+        refused(lib.evg_rollout_random(h, 3, 150, off(big_act, 8), p(obs), p(rew), p(done), None, None, None, None, None), b"actions_buf")
+        refused(lib.evg_rollout_policies(h, 3, 1, 1, 3, p(act), off(big_obs), p(rew), p(done), None, None, None, None, None), b"obs_out")
+        refused(lib.evg_step_vs_policy(h, 0, p(act), 1, 3, off(big_obs), p(rew), p(done), None, None, None, None), b"obs_seat_out")
+        refused(lib.evg_observe_seat(h, 0, off(big_obs), None), b"obs_seat_out")
+        refused(lib.evg_smart_state(h, 0, p(obs), off(torch.zeros((9, 12, 59), device="cuda")), None), b"features_out")
         ms = C.c_float()
         assert lib.evg_rollout_random(h, 0, 1, p(act), p(obs), p(rew), p(done), None, None, None, C.byref(ms), None) == -1
         assert lib.evg_rollout_policies(h, 5, 1, 77, 0, p(act), p(obs), p(rew), p(done), None, None, None, None, None) == -1

@@ -1,7 +1,7 @@
 """Shared by tools/pmc_summary.py and tools/sq_summary.py: reading rocprofv3 CSV output of the bench command and
 selecting the step-kernel dispatches of the TIMED window (the last 150 turns of the run; the pre-roll, settle and
 warm-up launches before them are not part of any reported figure)."""
-import csv, glob, hashlib, json, os
+import csv, glob, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FORMS = {"persistent": ("true, false>", 150, 1), "perturn": ("false, false>", 1, 150),     # kernel-name tail, turns per launch, step launches in the timed window
          "caller": ("false, false>", 1, 150),    # caller-supplied orders: per turn the action kernel(s) + the single-turn step kernel
@@ -13,12 +13,12 @@ KERNELS_PER_TURN = 1            # of the caller form: set by the summary scripts
 
 
 def kernel_source_hash():
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc")      # the files the product kernels are compiled from
-    for f in [os.path.join(csrc, n) for n in ("evg_device.h", "evg_kernels.hip", "evg_step4.inc", "evg_mt.h", "evg_rng.h")] + [os.path.join(ROOT, "include", "evg.h")]:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """the one definition: everglades_amd._lib.kernel_source_hash (what bench.py compares with)"""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import everglades_amd
+    return everglades_amd._lib.kernel_source_hash()
 
 
 OBS_CTYPE = {"float32": "float", "float64": "double", "int16": "short"}
