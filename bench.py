@@ -253,8 +253,9 @@ def compact_line(full):
         if not l:
             return None
         o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "turns_per_launch", "parts") if k in l}
-        if l.get("learner_vs_bot"):
-            o["learner_vs_bot"] = {k: _r(l["learner_vs_bot"][k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms")}
+        for sub in ("learner_vs_bot", "with_features"):
+            if l.get(sub):
+                o[sub] = {k: _r(l[sub][k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms")}
         if l.get("roofline"):
             o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}      # (bound, peak, unit and byte source: as in the main roofline object)
         return o
@@ -269,7 +270,8 @@ def compact_line(full):
                      **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash", "episodes_finished_rank0",
                                           "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
                      "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")),
-                     "learner_vs_bot_per_turn": leg(c.get("learner_vs_bot_per_turn")), "pipelined_halves_per_turn": leg(c.get("pipelined_halves_per_turn")),
+                     "learner_vs_bot_per_turn": leg(c.get("learner_vs_bot_per_turn")), "learner_smart_actions_vs_bot_per_turn": leg(c.get("learner_smart_actions_vs_bot_per_turn")),
+                     "pipelined_halves_per_turn": leg(c.get("pipelined_halves_per_turn")),
                      "obs_float64": leg(c.get("obs_float64")),
                      "without_observations": leg(c.get("without_observations"))}
     out["roofline"] = roof(full["roofline"])
@@ -512,7 +514,7 @@ def main():
 
     # ---- reference legs, outside the timed region (single GPU): one launch per turn (what env.step() costs per call), and the
     # reference's own observation dtype (float64)
-    per_turn_launch = caller_leg = learner_leg = obs_f64 = no_obs_leg = pipe_leg = None
+    per_turn_launch = caller_leg = learner_leg = obs_f64 = no_obs_leg = pipe_leg = smart_leg_ = None
     if world == 1 and not args.no_extra_legs:
         def per_turn_leg(fused):
             """150 turns, one step launch per turn, warmed; wall clock between two barriers and the stream time between two
@@ -533,6 +535,37 @@ def main():
             learner_leg = per_turn_leg("learner")
             learner_leg["path"] = ("per turn: evg_random_actions_seat -> caller tensor [N,7,2] (seat 0) -> evg_step_vs_policy(opponent = on-device `%s` on seat 1, evaluated inside the step "
                                    "kernel; only seat 0's observation [N,105] written) -- evaluate.py:85-93,143-152 with a learner on one seat" % args.opponent)
+        if main_fused is True and args.workload == "random":
+            # The learner-seat turn with the Smart_State family's own decode on the device: per turn evg_smart_actions(Q [N,12,5] -> 7 order rows: DQNAgent.get_best_actions) +
+            # evg_step_vs_policy; Q = one of 8 prepared random tensors (the stand-in for the consumer's network output: QNetwork 59-60-60-5 in the reference, not ours).
+            # A second figure adds evg_smart_state_compact (the network's input) in front: observation -> features -> [network] -> orders -> step, no host or framework glue.
+            qs = [torch.randn((n_local, 12, 5), device=device) for _ in range(8)]
+            sobs = env.observe_seat(0)
+            sh = torch.empty((n_local, 34), dtype=torch.float32, device=device)
+            sw = torch.empty((n_local, 12, 13), dtype=torch.float32, device=device)
+
+            def smart_turns(n, features):
+                for t_ in range(n):
+                    if features:
+                        env.smart_state_compact(-1, sobs, sh, sw)
+                    env.step_vs(args.opponent, env.smart_actions(qs[t_ & 7], obs=sobs), seat=0)      # (step_vs writes the next observation into sobs)
+
+            def smart_leg(features):
+                smart_turns(16, features)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); e1.record()
+                barrier()
+                t1 = time.perf_counter()
+                e0.record()
+                smart_turns(150, features)
+                e1.record()
+                barrier()
+                d1 = time.perf_counter() - t1
+                return {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": e0.elapsed_time(e1) / 150, "launches_per_turn": 3 if features else 2}
+            smart_leg_ = smart_leg(False)
+            smart_leg_["with_features"] = smart_leg(True)
+            smart_leg_["path"] = ("per turn, from a Python loop over the C-ABI: evg_smart_actions(Q [N,12,5] f32, one-seat obs) -> [N,7,2] orders (DQNAgent.get_best_actions on the device) -> "
+                                  "evg_step_vs_policy(opponent `%s` inside the step kernel); with_features: evg_smart_state_compact in front (the network's input)" % args.opponent)
         if main_fused is True:
             caller_leg = per_turn_leg(False)
             caller_leg["path"] = ("per turn: evg_random_actions -> caller tensor [N,2,7,2] -> evg_step(actions) (evaluate.py:143-152 with on-device agents)" if args.workload == "random" else
@@ -709,7 +742,7 @@ def main():
                                  "then 150 settle turns, --warmup turns and the K timed turns",
                        "envs_per_gpu": n_local, "total_envs": total, "turns_per_launch": tpl, "turns_of_last_timed_launch": turns_last_launch,
                        "launch_form": main_form,
-                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "learner_vs_bot_per_turn": learner_leg, "pipelined_halves_per_turn": pipe_leg, "obs_float64": obs_f64, "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
+                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "learner_vs_bot_per_turn": learner_leg, "learner_smart_actions_vs_bot_per_turn": smart_leg_, "pipelined_halves_per_turn": pipe_leg, "obs_float64": obs_f64, "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
                        "kernel_source_hash": kernel_source_hash(),
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],

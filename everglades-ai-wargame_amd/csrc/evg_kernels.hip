@@ -377,6 +377,21 @@ int launch_smart_state(const DevState& S, int player, const void* obs, int seat_
     return (int)hipGetLastError();
 }
 
+// network output -> orders: one DPP row (16 lanes) per env
+int launch_smart_actions(const DevState& S, int player, const void* obs, int seat_only, const float* q, int32_t* actions, int32_t* directions, int obs_dtype, void* stream) {
+    const dim3 grid((unsigned)(((size_t)S.N * 16 + 255) / 256)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int2* a = reinterpret_cast<int2*>(actions);
+    int2* d = reinterpret_cast<int2*>(directions);
+    switch (obs_dtype) {
+        case EVG_OBS_F32: hipLaunchKernelGGL(evg_smart_actions_kernel<float>, grid, block, 0, s, S.N, player, seat_only, (const float*)obs, q, a, d); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL(evg_smart_actions_kernel<double>, grid, block, 0, s, S.N, player, seat_only, (const double*)obs, q, a, d); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL(evg_smart_actions_kernel<int16_t>, grid, block, 0, s, S.N, player, seat_only, (const int16_t*)obs, q, a, d); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
 int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, int8_t* sight, void* stream) {
     hipLaunchKernelGGL(evg_fog_kernel, dim3((2 * S.N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, fog, know, sight);
     return (int)hipGetLastError();

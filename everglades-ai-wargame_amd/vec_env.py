@@ -327,6 +327,30 @@ class EvergladesVecEnv(object):
         self._check(self.L.evg_smart_state_compact(self._h, int(player), self._ptr(obs), self._ptr(shared), self._ptr(swarm), self._stream()))
         return shared, swarm
 
+    def smart_actions(self, q, player=0, obs=None, out=None, directions=None):
+        """Network output -> orders on the device (evg_smart_actions = DQNAgent.get_best_actions): `q` float32 [N, 12, 5], the policy network's Q values of
+        every swarm for the directions left / right / up / down / stay; `obs` the env's observation buffer, a [N, 2, 105] tensor (rows of seat `player`) or a
+        one-seat tensor [N, 105] (step_vs / observe_seat).  Returns int32 [N, 7, 2] {swarm, node}: what step_vs() takes as `actions` -- the seven swarms with
+        the LOWEST best Q, like the reference (ascending stable sort, first seven).  `directions`: an int32 [N, 7, 2] tensor that also receives {swarm, direction}."""
+        torch = _torch()
+        obs = self.obs if obs is None else obs
+        self._user(q, (self.num_envs, _lib.NUM_GROUPS, 5), torch.float32, "q")
+        if out is None:
+            self._seat_buffers()
+            out = self._actions_seat
+        self._user(out, (self.num_envs, _lib.NUM_ACTIONS, 2), self._int32, "out")
+        if directions is not None:
+            self._user(directions, (self.num_envs, _lib.NUM_ACTIONS, 2), self._int32, "directions")
+        if isinstance(obs, torch.Tensor) and obs.dim() == 2:
+            self._user(obs, (self.num_envs, _lib.OBS_LEN), self.obs_dtype, "obs")
+            player = -1
+        else:
+            self._user(obs, (self.num_envs, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
+        rc = self.L.evg_smart_actions(self._h, int(player), C.c_void_p(obs.data_ptr()), C.c_void_p(q.data_ptr()), C.c_void_p(out.data_ptr()), self._ptr(directions), self._stream())
+        if rc:
+            self._check(rc)
+        return out
+
     @staticmethod
     def expand_smart_state(shared, swarm):
         """[N, 12, 59] from the compact pair (for checks; a consumer would rather split its first layer's weights)."""

@@ -35,8 +35,9 @@
 extern "C" {
 #endif
 
-#define EVG_ABI_VERSION 4
-/* 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat, evg_smart_state_compact,
+#define EVG_ABI_VERSION 5
+/* 5: evg_smart_actions; every device buffer must be 16-byte aligned (checked)
+ * 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat, evg_smart_state_compact,
  *    evg_check_fault + EVG_ERR_FAULT, evg_pack_episode_results_counted, evg_config.cache_mib
  * 3: evg_launch_plan
  * 2: evg_pack_episode_results, node words as u32 */
@@ -223,6 +224,20 @@ EVG_API int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* fea
  * [N][2][105]; player -1: obs is a one-seat tensor [N][105]. */
 EVG_API int evg_smart_state_compact(evg_handle* h, int player, const void* obs, float* shared_out, float* swarm_out, void* stream);
 EVG_API void evg_move_table(int32_t* table);
+/* ... and the way back, network output -> orders: DQNAgent.get_best_actions (agents/Smart_State/DQNAgent.py:176-198) over swarm_think (:233-266),
+ * get_swarm_node_number (:302-310) and Move_Translation.get_move (Move_Translation.py:85-97).
+ *   q               device float [N][12][5]: the policy network's Q values of every swarm for the five directions left, right, up, down, stay (the network
+ *                   itself -- QNetwork 59-60-60-5 in the reference -- is the consumer's); 16-byte aligned
+ *   obs / player    as in evg_smart_state_compact: player 0 / 1 reads that seat's rows of [N][2][105], player -1 a one-seat tensor [N][105] (only the
+ *                   swarm locations obs[45 + 5 s] are read)
+ *   actions_out     device int32 [N][7][2]: {swarm, node} -- exactly the `actions` of evg_step_vs_policy (actions_both_seats == 0)
+ *   directions_out  device int32 [N][7][2] or NULL: {swarm, direction} (what the reference's replay memory stores)
+ * Every swarm's best direction is the FIRST maximum of its five Q values (torch.argmax), its order the node get_move gives for that direction from the
+ * swarm's location, and the seven rows are the first seven decisions of a STABLE ASCENDING sort by best Q: the reference acts with the seven swarms whose
+ * best Q is LOWEST (sorted(...)[:7], :189-197) -- reproduced as it is.  Q values must not be NaN (the reference's sort is undefined for them; here a NaN
+ * is a swarm's maximum, as in torch, and sorts like +inf).  With evg_smart_state(_seat / _compact) this closes the learner's turn on the device:
+ * observation -> features -> (consumer's network) -> orders -> evg_step_vs_policy, no host or framework glue between the kernels. */
+EVG_API int evg_smart_actions(evg_handle* h, int player, const void* obs, const float* q, int32_t* actions_out, int32_t* directions_out, void* stream);
 
 /* Input generator for the benchmark configs: the on-device equivalent of
  * agents/State_Machine/random_actions.py:38-46 for every env and both players, keyed by

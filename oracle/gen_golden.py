@@ -641,6 +641,41 @@ def gen_smart_state_fixture():
     print("smart_state:", feats.shape, moves.tolist(), flush=True)
 
 
+def gen_smart_actions_fixture():
+    """SURVEY 8 f4, the other half: network output -> orders.  DQNAgent.get_best_actions (agents/Smart_State/DQNAgent.py:176-198) over
+    get_all_swarm_decisions / swarm_think (:214-266), get_swarm_node_number (:302-310) and Move_Translation.get_move (:85-97), run by the
+    reference's own methods on an object created WITHOUT __init__ (no pickle, no network file): `policy_net` is a stub that returns the
+    prepared Q row of the swarm whose one-hot id the real create_swarm_obs put into its input.  Q tensors: random float32, part of them
+    quantised to a few levels so that swarms tie on best_q_value (the sort is stable and ASCENDING, and the agent keeps the FIRST seven:
+    the seven swarms with the lowest best Q -- a quirk, pinned here) and directions tie inside a swarm (torch.argmax: first maximum);
+    one all-equal tensor and one with +0.0 / -0.0."""
+    sys.path.insert(0, REF)
+    import torch
+    import agents.Smart_State.DQNAgent as D
+    d = np.load(os.path.join(OUT, "smart_state.npz"))
+    obs = d["obs"].astype(np.float64)                         # [M, 2, 105]: the observations of the feature fixture
+    M = obs.shape[0]
+    rng = np.random.default_rng(20261005)
+    q = rng.standard_normal((M, 2, NG, D.OUTPUT_SIZE)).astype(np.float32)
+    q[M // 3: 2 * M // 3] = np.round(q[M // 3: 2 * M // 3] * 2.0) / 2.0          # few levels: ties between swarms and between directions
+    q[2 * M // 3:] = np.round(q[2 * M // 3:])
+    q[0] = 0.25                                                                # everything ties
+    q[1, :, ::2] = 0.0
+    q[1, :, 1::2] = -0.0
+    agent = D.DQNAgent.__new__(D.DQNAgent)                    # no __init__: nothing is loaded
+    agent.num_nodes = NN
+    actions = np.zeros((M, 2, 7, 2), np.int32)
+    directions = np.zeros((M, 2, 7, 2), np.int32)
+    for m in range(M):
+        for p in range(2):
+            agent.policy_net = lambda swarm_obs, m=m, p=p: torch.from_numpy(q[m, p, int(np.argmax(swarm_obs[47:59]))].copy())
+            a, dr = agent.get_best_actions(obs[m, p])
+            assert a.shape == (7, 2) and np.array_equal(a, a.astype(np.int32)) and np.array_equal(dr, dr.astype(np.int32))
+            actions[m, p], directions[m, p] = a.astype(np.int32), dr.astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "smart_actions.npz"), obs=d["obs"], q=q, actions=actions, directions=directions)
+    print("smart_actions:", q.shape, actions[0, 0].tolist(), actions[M - 1, 1].tolist(), flush=True)
+
+
 # ----------------------------------------------------------------------------------------------
 # north-star acceptance sample: 10 000 seeded random-vs-random matches played by the reference
 # ----------------------------------------------------------------------------------------------
@@ -812,6 +847,7 @@ def main():
         return
     if os.environ.get("EVG_GOLDEN_ONLY") == "smart":
         gen_smart_state_fixture()
+        gen_smart_actions_fixture()
         return
     only = os.environ.get("EVG_GOLDEN_ONLY")
 
@@ -847,6 +883,7 @@ def main():
     gen_agent_fixtures(R)
 
     gen_smart_state_fixture()
+    gen_smart_actions_fixture()
     gen_stock_mt_fixture(R)
     gen_config1_fixture(R)
 

@@ -86,6 +86,7 @@ def lib():
         L.evo_mt_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.evo_mt_randint_stream.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.evo_smart_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.evo_smart_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.evo_get_move.restype = C.c_int
         L.evo_get_move.argtypes = [C.c_int, C.c_int]
         L.evo_fog_of_war.argtypes = [C.c_void_p, C.c_void_p]
@@ -234,6 +235,17 @@ def smart_state(obs_rows):
     out = np.zeros((o.shape[0], NG, 59), np.float64)
     lib().evo_smart_state(_p(o), o.shape[0], _p(out))
     return out
+
+
+def smart_actions(q, obs_rows):
+    """q [m, 12, 5] float32 (the policy network's output per swarm), obs_rows [m, 105] -> (actions [m, 7, 2], directions [m, 7, 2]) int32:
+    DQNAgent.get_best_actions (the seven swarms with the LOWEST best Q, ascending stable sort)."""
+    qq = np.ascontiguousarray(q, np.float32)
+    o = np.ascontiguousarray(obs_rows, np.float64)
+    a = np.zeros((o.shape[0], 7, 2), np.int32)
+    d = np.zeros((o.shape[0], 7, 2), np.int32)
+    lib().evo_smart_actions(_p(qq), _p(o), o.shape[0], _p(a), _p(d))
+    return a, d
 
 
 def get_move(node0, direction):

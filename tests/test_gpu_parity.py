@@ -539,6 +539,51 @@ def test_smart_state_multi_pass_ragged_vs_oracle(evg, oracle_mod):
     env.close()
 
 
+def test_smart_actions_match_reference_fixture_and_oracle(evg, oracle_mod):
+    """SURVEY 8 f4, network output -> orders (evg_smart_actions): device == DQNAgent.get_best_actions as the reference's own methods computed it
+    (tests/golden/smart_actions.npz: Q tensors with ties between swarms and between directions, all-equal, +0.0 / -0.0) for every observation dtype,
+    from the two-seat tensor and from a one-seat tensor; then a ragged 65 536 + 37-env batch of mid-game observations with quantised Q values
+    (ties everywhere) against the oracle's restatement, both seats; and the rows go straight into step_vs()."""
+    import torch
+    d = load_golden("smart_actions.npz")
+    M = d["obs"].shape[0]
+    for dt, tdt in (("float32", torch.float32), ("float64", torch.float64), ("int16", torch.int16)):
+        env = evg.EvergladesVecEnv(M, seed=1, obs_dtype=dt)
+        obs = torch.as_tensor(d["obs"].astype(np.int64), device=env.device).to(tdt).contiguous()
+        for p in range(2):
+            q = torch.as_tensor(d["q"][:, p], device=env.device).contiguous()
+            dirs = torch.zeros((M, 7, 2), dtype=torch.int32, device=env.device)
+            a = env.smart_actions(q, p, obs, directions=dirs)
+            assert np.array_equal(_np(a), d["actions"][:, p]) and np.array_equal(_np(dirs), d["directions"][:, p]), (dt, p)
+            a1 = env.smart_actions(q, obs=obs[:, p].contiguous(), out=torch.zeros((M, 7, 2), dtype=torch.int32, device=env.device))      # one-seat tensor
+            assert np.array_equal(_np(a1), d["actions"][:, p]), (dt, p, "one-seat")
+        env.close()
+    N = 65536 + 37
+    env = evg.EvergladesVecEnv(N, seed=12, auto_reset=True)
+    env.reset()
+    env.rollout_random(60, turns_per_launch=60)
+    obs = _np(env.obs).astype(np.float64)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for p in range(2):
+        q = (torch.randn((N, 12, 5), generator=g) * 2.0).round().div(2.0).to(env.device)           # few levels: ties between swarms and directions
+        dirs = torch.zeros((N, 7, 2), dtype=torch.int32, device=env.device)
+        got = _np(env.smart_actions(q, p, directions=dirs))
+        want_a, want_d = oracle_mod.smart_actions(_np(q), obs[:, p])
+        assert np.array_equal(got, want_a) and np.array_equal(_np(dirs), want_d), p
+    # ... and the rows are what the learner-seat turn takes: features -> (a stand-in network) -> orders -> step, nothing on the host in between
+    sobs = env.observe_seat(0)
+    feats = env.smart_state(0, sobs)
+    w = torch.randn((59, 5), generator=g).to(env.device)
+    rows = env.smart_actions((feats @ w).contiguous(), obs=sobs)
+    want_a, _ = oracle_mod.smart_actions(_np(feats @ w), _np(sobs).astype(np.float64))
+    assert np.array_equal(_np(rows), want_a)
+    o2, rew, done, info = env.step_vs("random", rows, seat=0)
+    assert o2.shape == (N, 105) and int(info["status"].max()) <= 3
+    with pytest.raises(ValueError):
+        env.smart_actions(torch.zeros((N, 12, 4), device=env.device))
+    env.close()
+
+
 @pytest.mark.parametrize("tpl", [2, 7, 150])
 def test_persistent_multi_turn_rollout_equals_stepwise(evg, oracle_mod, tpl):
     """The persistent rollout form (each launch plays `tpl` consecutive turns per wavefront with the state resident on

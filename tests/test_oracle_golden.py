@@ -291,3 +291,27 @@ def test_ten_thousand_reference_matches_config5(oracle_mod):
             return obs.sum(axis=2).astype(np.int32), obs[:, :, 49::5].sum(axis=2).astype(np.int16), info["scores"], info["status"], rew, done
         return step
     check_matches(play_matches(make, d), d)
+
+
+def test_smart_state_and_smart_actions_oracle_vs_reference_fixtures(oracle_mod):
+    """SURVEY 8 f4, both halves, oracle == the reference's own methods: create_swarm_obs (smart_state.npz) and get_best_actions over
+    swarm_think / get_swarm_node_number / Move_Translation.get_move (smart_actions.npz: random Q tensors with ties, an all-equal one,
+    +0.0 / -0.0; rows = the seven swarms with the LOWEST best Q, ascending stable sort -- the reference's quirk)."""
+    d = load_golden("smart_state.npz")
+    for p in range(2):
+        assert np.array_equal(oracle_mod.smart_state(d["obs"][:, p].astype(np.float64)), d["features"][:, p]), p
+    a = load_golden("smart_actions.npz")
+    assert np.array_equal(a["obs"], d["obs"]) and a["q"].dtype == np.float32 and a["q"].shape[1:] == (2, 12, 5)
+    for p in range(2):
+        act, dr = oracle_mod.smart_actions(a["q"][:, p], a["obs"][:, p].astype(np.float64))
+        assert np.array_equal(act, a["actions"][:, p]) and np.array_equal(dr, a["directions"][:, p]), p
+    # the fixture does exercise the quirks: ties between swarms (stable order decides) and rows that are NOT the seven highest Q
+    bq = a["q"].max(axis=3)                                            # [M, 2, 12]
+    assert (np.sort(bq, axis=2)[:, :, 6] == np.sort(bq, axis=2)[:, :, 7]).any()
+    chosen_max = np.take_along_axis(bq, a["actions"][..., 0], axis=2).max(axis=2)
+    assert (chosen_max <= np.sort(bq, axis=2)[:, :, 6]).all()          # every chosen swarm is among the seven lowest
+    for m in range(a["q"].shape[0]):
+        for p in range(2):
+            for i in range(7):
+                sw, node = a["actions"][m, p, i]
+                assert node == oracle_mod.get_move(int(a["obs"][m, p, 45 + 5 * sw]) - 1, int(a["directions"][m, p, i, 1]))

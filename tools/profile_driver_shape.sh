@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_${NAME}_driver
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-extra-legs > $OUT/bench.json 2> $OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $OUT/bench.json 2> $OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
 cd $R
 python3 - <<PY
 import csv, glob, json
@@ -17,7 +17,7 @@ rows.sort()
 pers = [(i, n, d) for i, n, d in rows if "evg_step_kernel<float, 64, true, false, false, false>" in n]
 line = json.loads([l for l in open("$OUT/bench.json") if l.startswith("{")][-1])
 stats = open(glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]).read().splitlines()
-out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-extra-legs"',
+out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs"',
        '"# persistent step-kernel dispatches of the run, in order (ns): %s"' % " ".join(str(d) for _, _, d in pers),
        '"# the LAST one is the timed 20-turn launch: %d ns = %.2f us per turn; the line of the same run says roofline.kernel_ms = %.5f (x 20 turns = %.1f us between the two stream events), ms_per_step = %.5f"'
        % (pers[-1][2], pers[-1][2] / 20 / 1e3, line["roofline"]["kernel_ms"], line["roofline"]["kernel_ms"] * 20 * 1e3, line["ms_per_step"]),
