@@ -11,11 +11,11 @@ from .tables import default_tables, tables_from_json
 from .vec_env import EvergladesVecEnv
 from .pipeline import PipelinedVecEnv
 from .env import EvergladesEnv, canonical_actions
-from .distributed import shard_range, gather_episode_results, win_counts, ResultGather
+from .distributed import shard_range, gather_episode_results, win_counts, ResultGather, NativeGather
 from .harness import evaluate, evaluate_all, proportion_confint_normal
 
 __all__ = ["EvergladesVecEnv", "PipelinedVecEnv", "EvergladesEnv", "EvgError", "EvgFault", "load_library", "default_tables", "tables_from_json",
-           "canonical_actions", "shard_range", "gather_episode_results", "win_counts", "ResultGather", "evaluate", "evaluate_all",
+           "canonical_actions", "shard_range", "gather_episode_results", "win_counts", "ResultGather", "NativeGather", "evaluate", "evaluate_all",
            "proportion_confint_normal"]
 
 try:  # optional: same gym id as the reference (gym_everglades/__init__.py:3-6) when gym is installed

@@ -16,6 +16,8 @@ NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11,
 MAX_SCORE = 3700
 OBS_F32, OBS_F64, OBS_I16 = 0, 1, 2
 ABI_VERSION = 5
+ERR_COMM = -6         # EVG_ERR_COMM: RCCL missing or one of its calls failed (evg_comm_*, evg_gather_returns)
+COMM_ID_BYTES = 128
 ERR_FAULT = -5        # EVG_ERR_FAULT: the handle's fault word is set (evg_check_fault)
 RNG_KEYED_PHILOX, RNG_STOCK_MT19937 = 0, 1
 POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "all_cycle", "base_rush_v1", "bull_rush",
@@ -24,7 +26,7 @@ POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "al
 POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
 EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat", "evg_random_actions_seat", "evg_smart_state_seat", "evg_smart_state_compact", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war", "evg_sightings", "evg_smart_state", "evg_smart_actions", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
-           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_pack_episode_results_counted", "evg_launch_plan", "evg_num_envs",
+           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_pack_episode_results_counted", "evg_comm_unique_id", "evg_comm_init", "evg_gather_returns", "evg_comm_destroy", "evg_launch_plan", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
 
@@ -158,6 +160,10 @@ def load(path=None):
     L.evg_episode_stats_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.evg_pack_episode_results.argtypes = [vp, vp, vp]
     L.evg_pack_episode_results_counted.argtypes = [vp, vp, vp, vp]
+    L.evg_comm_unique_id.argtypes = [vp]
+    L.evg_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.evg_gather_returns.argtypes = [vp, C.c_int, vp, vp]
+    L.evg_comm_destroy.argtypes = [vp]
     L.evg_launch_plan.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
     L.evg_num_envs.argtypes = [vp]
     L.evg_state_bytes_per_env.argtypes = [vp]

@@ -2,11 +2,14 @@
 // Owns the persistent device state of one handle, validates and flattens the constant tables,
 // and enqueues the kernels of evg_kernels.hip on the caller's stream.  No CPU execution path.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>       // types and prototypes only: librccl is opened at run time (dlopen), libevg.so has no NEEDED entry for it
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "evg_device.h"
@@ -100,6 +103,11 @@ struct evg_handle {
 #endif
     std::vector<void*> allocs;
     std::vector<hipEvent_t> events;     // evg_rollout_random timing
+    // the path's one exchange without torch.distributed (evg_comm_init / evg_gather_returns): an RCCL communicator of this handle's device
+    ncclComm_t comm = nullptr;
+    int comm_world = 0, comm_rank = -1;
+    std::vector<int32_t> comm_counts;   // envs of every rank's handle (contiguous shards in rank order)
+    float* comm_send = nullptr;         // device [N][4]: this handle's packed rows, where the collective reads them
 #ifdef EVG_DIAG                         // diagnostic libraries only, set through evg_diag_configure (never from the environment)
     uint32_t ablate = 0;
     int32_t lanes = 0;                  // diagnostic library: 0 = the product's choice of step kernel, else evg_diag_configure's
@@ -578,6 +586,7 @@ void evg_destroy(evg_handle* h) {
     if (!h) return;
     DeviceGuard guard(h->cfg.device_id);
     drop_graphs(h);
+    (void)evg_comm_destroy(h);
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->fault_seen_host) (void)hipHostFree(h->fault_seen_host);
@@ -1047,10 +1056,11 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
  *   lanes_per_wave  0 (default: what the product library launches), 2 (experiment: persistent rollouts of a batch beyond what the device holds run the
  *                   CHUNKED form over the whole batch, i.e. with a working set larger than the Infinity Cache), 64 (the two-lanes-per-env kernel at every batch
  *                   size and in both
- *                   launch forms), 32 (16 envs per wavefront + 32 helper lanes) or 4 (the four-lanes-per-env kernel in both launch forms)
+ *                   launch forms), 32 (16 envs per wavefront + 32 helper lanes), 4 (the four-lanes-per-env kernel in both launch forms) or 256 (single-turn
+ *                   launches as 256-thread workgroups of four independent wavefronts: the round-5 dispatch experiment)
  *   force_ieee_div  != 0: run the step kernel's true-division branch although the table set passed the exact-quotient check */
 EVG_API int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) {
-    if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4 && lanes_per_wave != 2))
+    if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4 && lanes_per_wave != 2 && lanes_per_wave != 256))
         return fail(EVG_ERR_INVALID, "diag: bad argument");
     EVG_ON_DEVICE(h);
     h->ablate = ablate;
@@ -1137,6 +1147,135 @@ int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t* counts_
     EVG_ON_DEVICE(h);
     const int rc = launch_pack_results(h->S, out, reinterpret_cast<long long*>(counts_out), stream);
     if (rc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The path's one exchange between GPUs for callers that have no torch.distributed (SURVEY 8b `evg_gather_returns`, 8e): RCCL itself, opened at run time.
+// In a PyTorch process dlopen("librccl.so.1") resolves to the instance torch has already loaded (same SONAME); a plain C client gets ROCm's.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+
+const RcclApi* rccl() {
+    std::call_once(g_rccl_once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.lib) break;
+        }
+        if (!g_rccl.lib) { g_rccl.why = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "?") + ")"; return; }
+        auto sym = [](const char* n) { return dlsym(g_rccl.lib, n); };
+        g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
+        g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
+        g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+        g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(sym("ncclGroupStart"));
+        g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
+        g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
+        g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
+        g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Send || !g_rccl.Recv ||
+            !g_rccl.GetErrorString) {
+            g_rccl.why = "librccl lacks an entry point of the send / receive API";
+            g_rccl.lib = nullptr;
+        }
+    });
+    return g_rccl.lib ? &g_rccl : nullptr;
+}
+
+#define RCCL_TRY(R, expr)                                                                                        \
+    do {                                                                                                         \
+        const ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) return fail(EVG_ERR_COMM, "%s failed: %s", #expr, (R)->GetErrorString(r_));       \
+    } while (0)
+}  // namespace
+
+int evg_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(EVG_ERR_INVALID, "null argument");
+    const RcclApi* R = rccl();
+    if (!R) return fail(EVG_ERR_COMM, "RCCL is not available: %s", g_rccl.why.c_str());
+    static_assert(sizeof(ncclUniqueId) == EVG_COMM_ID_BYTES, "evg.h: EVG_COMM_ID_BYTES");
+    ncclUniqueId id;
+    RCCL_TRY(R, R->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return EVG_OK;
+}
+
+int evg_comm_init(evg_handle* h, const void* id, int world, int rank, const int32_t* counts) {
+    if (!h || !id || !counts || world < 1 || rank < 0 || rank >= world) return fail(EVG_ERR_INVALID, "comm_init: bad argument");
+    if (h->comm) return fail(EVG_ERR_INVALID, "comm_init: the handle already has a communicator (evg_comm_destroy first)");
+    long long total = 0;
+    for (int r = 0; r < world; ++r) {
+        if (counts[r] < 1) return fail(EVG_ERR_INVALID, "comm_init: counts[%d] = %d", r, counts[r]);
+        total += counts[r];
+    }
+    if (counts[rank] != h->S.N) return fail(EVG_ERR_INVALID, "comm_init: counts[%d] = %d, but this handle has %d envs", rank, counts[rank], h->S.N);
+    if (total > 0x7FFFFFFFll) return fail(EVG_ERR_INVALID, "comm_init: more than 2^31 envs in all");
+    const RcclApi* R = rccl();
+    if (!R) return fail(EVG_ERR_COMM, "RCCL is not available: %s", g_rccl.why.c_str());
+    EVG_ON_DEVICE(h);
+    if (!h->comm_send) {
+        const int rc = dev_alloc(h, &h->comm_send, (size_t)h->S.N * 4);
+        if (rc) return rc;
+    }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t c = nullptr;
+    RCCL_TRY(R, R->CommInitRank(&c, world, uid, rank));          // collective: returns when every rank has called
+    h->comm = c; h->comm_world = world; h->comm_rank = rank;
+    h->comm_counts.assign(counts, counts + world);
+    return EVG_OK;
+}
+
+int evg_gather_returns(evg_handle* h, int root, float* recv_out, void* stream) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (!h->comm) return fail(EVG_ERR_INVALID, "gather_returns: no communicator (evg_comm_init)");
+    if (root < 0 || root >= h->comm_world) return fail(EVG_ERR_INVALID, "gather_returns: root %d of %d ranks", root, h->comm_world);
+    if ((h->comm_rank == root) != (recv_out != nullptr)) return fail(EVG_ERR_INVALID, "gather_returns: recv_out is required on the root rank and must be NULL elsewhere");
+    EVG_NEED_ALIGNED16(recv_out);
+    const RcclApi* R = rccl();
+    if (!R) return fail(EVG_ERR_COMM, "RCCL is not available: %s", g_rccl.why.c_str());
+    EVG_ON_DEVICE(h);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int prc = launch_pack_results(h->S, h->comm_send, nullptr, stream);      // poisoned rows if the handle's fault word is set
+    if (prc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)prc));
+    // one grouped operation on the caller's stream: every rank sends its rows to the root, the root receives every rank's rows at its offset (global env order)
+    RCCL_TRY(R, R->GroupStart());
+    ncclResult_t r1 = R->Send(h->comm_send, (size_t)h->S.N * 4, ncclFloat, root, h->comm, s);
+    if (r1 == ncclSuccess && recv_out) {
+        size_t at = 0;
+        for (int r = 0; r < h->comm_world && r1 == ncclSuccess; ++r) {
+            r1 = R->Recv(recv_out + at * 4, (size_t)h->comm_counts[r] * 4, ncclFloat, r, h->comm, s);
+            at += (size_t)h->comm_counts[r];
+        }
+    }
+    const ncclResult_t r2 = R->GroupEnd();
+    if (r1 != ncclSuccess) return fail(EVG_ERR_COMM, "ncclSend / ncclRecv failed: %s", R->GetErrorString(r1));
+    if (r2 != ncclSuccess) return fail(EVG_ERR_COMM, "ncclGroupEnd failed: %s", R->GetErrorString(r2));
+    return EVG_OK;
+}
+
+int evg_comm_destroy(evg_handle* h) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    if (!h->comm) return EVG_OK;
+    const RcclApi* R = rccl();
+    EVG_ON_DEVICE(h);
+    (void)hipDeviceSynchronize();
+    if (R) (void)R->CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_world = 0; h->comm_rank = -1;
+    h->comm_counts.clear();
     return EVG_OK;
 }
 

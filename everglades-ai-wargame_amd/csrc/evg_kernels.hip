@@ -90,6 +90,22 @@ static int launch_step_variant(const DevState& S, const StepIO& io, int obs_dtyp
     return (int)hipGetLastError();
 }
 
+#ifdef EVG_DIAG
+// round-5 experiment (diagnostic library, lanes = 256): the single-turn form with FOUR independent wavefronts per 256-thread workgroup
+static int launch_step_wg256(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
+    const int nsets = (io.env_hi - io.env_lo + WG / 2 - 1) / (WG / 2);
+    const dim3 grid((unsigned)((nsets + 3) / 4)), block(4 * WG);
+    const StepArgs args{S, io};
+    switch (obs_dtype) {
+        case EVG_OBS_F32: hipLaunchKernelGGL((evg_step_kernel<float, WG, false, false, false, false, 4>), grid, block, 0, s, args); break;
+        case EVG_OBS_F64: hipLaunchKernelGGL((evg_step_kernel<double, WG, false, false, false, false, 4>), grid, block, 0, s, args); break;
+        case EVG_OBS_I16: hipLaunchKernelGGL((evg_step_kernel<int16_t, WG, false, false, false, false, 4>), grid, block, 0, s, args); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+#endif
+
 // the chunked form of the persistent two-lane kernel: as many workgroups as the device holds, each taking units from its XCD's queue
 static int launch_step_chunked(const DevState& S, const StepIO& io, int obs_dtype, hipStream_t s) {
     const dim3 grid((unsigned)io.grid_slots), block(WG);
@@ -257,6 +273,7 @@ int launch_step(const DevState& S, const StepIO& io_in, int obs_dtype, const Dev
 #ifdef EVG_DIAG
     // the two-lane kernel at any size
     if (io.lanes_per_wave == 64) return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_variant<64, false>(S, io, obs_dtype, s);
+    if (io.lanes_per_wave == 256) return multi ? launch_step_variant<64, true>(S, io, obs_dtype, s) : launch_step_wg256(S, io, obs_dtype, s);
     if (io.lanes_per_wave == 4) return multi ? launch_step4<true, 4>(S, io, obs_dtype, s) : launch_step4<false, 4>(S, io, obs_dtype, s);
     if (io.lanes_per_wave == 32) return multi ? launch_step_variant<32, true>(S, io, obs_dtype, s) : launch_step_variant<32, false>(S, io, obs_dtype, s);
 #endif

@@ -157,6 +157,50 @@ class ResultGather:
         return (int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum()))
 
 
+class NativeGather:
+    """The same exchange WITHOUT torch.distributed: RCCL through the C-ABI (evg_comm_unique_id / evg_comm_init / evg_gather_returns, include/evg.h) -- what a
+    consumer without a framework uses (examples/c_client.c), and one launch cheaper on the stream than the torch form: the pack kernel and one grouped RCCL
+    send / receive run directly on the caller's stream.
+
+        cid = NativeGather.unique_id() on ONE rank; hand the 128 bytes to every rank (file, socket, a torch store ...)
+        g = NativeGather(env, total, world, rank, cid)      # collective: blocks until every rank has called (ncclCommInitRank)
+        full = g()                                           # collective, enqueued on torch's current stream: [total, 4] on rank `root`, None elsewhere
+    """
+
+    def __init__(self, env, total_envs, world, rank, comm_id, root=0):
+        import ctypes as C
+        import numpy as np
+        import torch
+        self.env, self.total, self.world, self.rank, self.root = env, int(total_envs), int(world), int(rank), int(root)
+        self.counts = [shard_range(self.total, self.world, r)[1] for r in range(self.world)]
+        if self.counts[self.rank] != env.num_envs:
+            raise ValueError("this handle has %d envs, shard_range(%d, %d, %d) gives %d" % (env.num_envs, self.total, self.world, self.rank, self.counts[self.rank]))
+        if len(comm_id) != 128:
+            raise ValueError("comm_id must be the 128 bytes of NativeGather.unique_id()")
+        cnt = np.asarray(self.counts, np.int32)
+        buf = C.create_string_buffer(bytes(comm_id), 128)
+        env._check(env.L.evg_comm_init(env._h, buf, self.world, self.rank, cnt.ctypes.data_as(C.c_void_p)))
+        self.recv = torch.empty((self.total, 4), dtype=torch.float32, device=env.device) if self.rank == self.root else None
+
+    @staticmethod
+    def unique_id(library=None):
+        import ctypes as C
+        from . import _lib
+        L = _lib.load(library)
+        buf = C.create_string_buffer(128)
+        _lib.check(L.evg_comm_unique_id(buf), L)
+        return buf.raw
+
+    def __call__(self):
+        import ctypes as C
+        env = self.env
+        env._check(env.L.evg_gather_returns(env._h, self.root, None if self.recv is None else C.c_void_p(self.recv.data_ptr()), env._stream()))
+        return self.recv
+
+    def close(self):
+        self.env._check(self.env.L.evg_comm_destroy(self.env._h))
+
+
 def _refuse_poisoned(w):
     """Rows with winner -2 come from a handle whose fault word is set (evg_pack_episode_results poisons them): its results are not valid."""
     if bool((w == -2).any()):

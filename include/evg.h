@@ -36,7 +36,8 @@ extern "C" {
 #endif
 
 #define EVG_ABI_VERSION 5
-/* 5: evg_smart_actions; every device buffer must be 16-byte aligned (checked)
+/* 5: evg_smart_actions; evg_comm_unique_id / evg_comm_init / evg_gather_returns / evg_comm_destroy + EVG_ERR_COMM; every device buffer must be
+ *    16-byte aligned (checked)
  * 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat, evg_smart_state_compact,
  *    evg_check_fault + EVG_ERR_FAULT, evg_pack_episode_results_counted, evg_config.cache_mib
  * 3: evg_launch_plan
@@ -62,7 +63,8 @@ typedef enum evg_status {
     EVG_ERR_NO_DEVICE = -2,    /* no usable HIP device (there is no CPU path)        */
     EVG_ERR_HIP = -3,          /* a HIP runtime call failed                         */
     EVG_ERR_ALLOC = -4,
-    EVG_ERR_FAULT = -5         /* the handle's fault word is set (evg_check_fault): its results are not valid, destroy it */
+    EVG_ERR_FAULT = -5,        /* the handle's fault word is set (evg_check_fault): its results are not valid, destroy it */
+    EVG_ERR_COMM = -6          /* RCCL is not available or one of its calls failed (evg_comm_*, evg_gather_returns)          */
 } evg_status;
 
 typedef enum evg_obs_dtype { EVG_OBS_F32 = 0, EVG_OBS_F64 = 1, EVG_OBS_I16 = 2 } evg_obs_dtype;
@@ -372,6 +374,27 @@ EVG_API int evg_pack_episode_results(evg_handle* h, float* out, void* stream);
  * rows without a finished episode (zeroed and filled on `stream`; all four are -1 when the rows are poisoned).  What a multi-GPU run
  * all-reduces next to the gather: the sum over ranks must equal what rank 0 counts in the gathered rows (bench.py). */
 EVG_API int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t* counts_out, void* stream);
+
+/* ---- Multi-GPU without torch.distributed: the path's ONE exchange over RCCL itself (SURVEY 8b `evg_gather_returns`, 8e) ----------------------------
+ * Environments shard over GPUs by contiguous global id (env_id_base), one process and one handle per GPU, and nothing is exchanged but the per-env
+ * results of finished episodes (win bookkeeping, evaluate.py:155-181).  A Python caller uses everglades_amd.ResultGather (torch.distributed, backend
+ * "nccl" = RCCL); a caller without torch -- examples/c_client.c -- uses these four entry points.  librccl is opened at run time (dlopen("librccl.so.1"):
+ * in a PyTorch process that is the instance torch already loaded); libevg.so itself does not depend on it, and the calls return EVG_ERR_COMM where RCCL is
+ * missing.
+ *   evg_comm_unique_id   ONE rank makes the communicator's id (ncclGetUniqueId); the caller hands the EVG_COMM_ID_BYTES bytes to every rank by its own means
+ *                        (a file, a socket, MPI, an environment variable)
+ *   evg_comm_init        every rank, collectively (it blocks until all `world` ranks have called): communicator of this handle's device.  counts: HOST
+ *                        int32 [world], the num_envs of every rank's handle -- contiguous shards in rank order; counts[rank] must be this handle's
+ *   evg_gather_returns   every rank, collectively, enqueued on `stream` (no synchronisation): evg_pack_episode_results of this handle + one grouped RCCL
+ *                        send / receive.  recv_out: on rank `root` device float [sum(counts)][4], 16-byte aligned -- the rows {return p0, return p1,
+ *                        winner, length} of ALL envs in global env order --, NULL on every other rank.  A rank whose handle is faulted sends poisoned rows
+ *                        (winner -2), as evg_pack_episode_results does
+ *   evg_comm_destroy     releases the communicator (evg_destroy does it as well) */
+#define EVG_COMM_ID_BYTES 128
+EVG_API int evg_comm_unique_id(void* id_out);
+EVG_API int evg_comm_init(evg_handle* h, const void* id, int world, int rank, const int32_t* counts);
+EVG_API int evg_gather_returns(evg_handle* h, int root, float* recv_out, void* stream);
+EVG_API int evg_comm_destroy(evg_handle* h);
 
 /* Which step kernel(s) a rollout launch of `turns_per_launch` turns runs for this handle's batch on this device, as text in
  * buf (for benchmark records and logs): the kernel mapping (two / four lanes per env), the env range and wavefront count of

@@ -4,9 +4,10 @@ ids, plays a persistent rollout with auto-reset and sends its packed episode res
 shard's final state must equal ONE oracle run of the total size -- i.e. the oracle, not the ranks themselves, checks what the
 transport carried.
 
-Three transports of the same child program:
+Transports of the same child program:
   gloo, 2 ranks on GPU 0          runs on every box (the collective on host copies)
   nccl (= RCCL), 1 rank           runs on every box: process-group, device buffers and the RCCL launch of the gather, nothing on the wire
+  evg_gather_returns, 1 rank      runs on every box: RCCL through the C-ABI (no torch.distributed), one rank; one rank per GPU like the nccl form below
   nccl, one rank per visible GPU  needs >= 2 GPUs (xGMI); BASELINE config 4 at its full size (8 x 65 536) when 8 are visible.  SKIPPED on the
                                   one-GPU boxes this repository has been developed on: RCCL has not carried a row between two GPUs in any
                                   round, and this is the test that checks it the day a multi-GPU box runs the suite."""
@@ -35,29 +36,58 @@ torch.cuda.set_device(dev)
 device = torch.device("cuda", dev)
 if backend == "nccl":
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-else:
+elif backend == "gloo":
     dist.init_process_group("gloo", rank=rank, world_size=world)
 first, cnt = evg.shard_range(total, world, rank)
 env = evg.EvergladesVecEnv(cnt, device=device, seed=seed, env_id_base=first, auto_reset=True)
 env.reset()
 env.rollout_random(steps, turns_per_launch=150)                        # persistent form: launches of 150 and steps - 150 turns
-g = evg.ResultGather(cnt, total, device, force=True)                  # (force: the one-rank group runs the collective too)
 counts = torch.zeros(4, dtype=torch.int64, device=device)
-full = g(env.packed_episode_results(out=g.buffer, counts=counts))     # THE collective of the path: pack kernel + gather to rank 0
+if backend == "evg":
+    # no torch.distributed at all: RCCL through the C-ABI (evg_comm_unique_id / evg_comm_init / evg_gather_returns).  The communicator's id travels in a file.
+    import time
+    idf = os.path.join(out_dir, "comm_id.bin")
+    if rank == 0:
+        open(idf + ".tmp", "wb").write(evg.NativeGather.unique_id())
+        os.rename(idf + ".tmp", idf)
+    t0 = time.time()
+    while not os.path.exists(idf):
+        assert time.time() - t0 < 120, "no communicator id from rank 0"
+        time.sleep(0.05)
+    g = evg.NativeGather(env, total, world, rank, open(idf, "rb").read())
+    full = g()                                                         # THE collective of the path: pack kernel + grouped RCCL send / receive to rank 0
+    env.packed_episode_results(counts=counts)
+    torch.cuda.synchronize(device)
+    summed, collective, backend_name = None, "gather", "evg_gather_returns"
+    class g_:                                                          # (rows_per_rank of the torch form, for the parent's checks)
+        @staticmethod
+        def rows_per_rank(full):
+            w, out, at = full[:, 2].cpu(), [], 0
+            for c in g.counts:
+                out.append(int((w[at:at + c] >= 0).sum())); at += c
+            return out
+    rows_per_rank = g_.rows_per_rank
+else:
+    g = evg.ResultGather(cnt, total, device, force=True)              # (force: the one-rank group runs the collective too)
+    full = g(env.packed_episode_results(out=g.buffer, counts=counts)) # THE collective of the path: pack kernel + gather to rank 0
+    summed = counts.clone() if backend == "nccl" else counts.cpu()
+    dist.all_reduce(summed)                                            # the ranks' own win counts (bench.py's self-check), outside the path
+    torch.cuda.synchronize(device)
+    collective, backend_name, rows_per_rank = g.collective, str(dist.get_backend()), g.rows_per_rank
 assert (full is None) == (rank != 0)
-summed = counts.clone() if backend == "nccl" else counts.cpu()
-dist.all_reduce(summed)                                                # the ranks' own win counts (bench.py's self-check), outside the path
-torch.cuda.synchronize(device)
 s = env.get_state()
 np.savez(os.path.join(out_dir, "rank%d.npz" % rank), first=first, cnt=cnt, groups=s["groups"], nodes=s["nodes"], health=s["health"], env=s["env"],
          actions=env._actions.cpu().numpy(), totals=env.episode_stats()["totals"], counts=counts.cpu().numpy(), device=dev,
          device_name=torch.cuda.get_device_name(dev))
 if rank == 0:
-    np.savez(os.path.join(out_dir, "gathered.npz"), rows=full.cpu().numpy(), wins=np.array(evg.ResultGather.win_counts(full)), summed=summed.cpu().numpy(),
-             rows_per_rank=np.array(g.rows_per_rank(full)), collective=g.collective, backend=str(dist.get_backend()))
+    np.savez(os.path.join(out_dir, "gathered.npz"), rows=full.cpu().numpy(), wins=np.array(evg.ResultGather.win_counts(full)),
+             summed=summed.cpu().numpy() if summed is not None else np.zeros(0, np.int64), rows_per_rank=np.array(rows_per_rank(full)), collective=collective, backend=backend_name)
+if backend == "evg":
+    g.close()
 env.close()
-dist.barrier()
-dist.destroy_process_group()
+if backend != "evg":
+    dist.barrier()
+    dist.destroy_process_group()
 """
 
 
@@ -103,7 +133,8 @@ def _run_ranks(tmp_path, oracle_mod, backend, world, ndev, total, seed=20261005,
     assert np.allclose(rows[:, :2], ost["returns"], rtol=0, atol=1e-4)
     w = ost["winner"]
     want = [int((w == 0).sum()), int((w == 1).sum()), int((w == 2).sum()), int((w < 0).sum())]
-    assert g["wins"].tolist() == want and g["summed"].tolist() == want and sum(want[:3]) == total         # win rule evaluate.py:155-160
+    assert g["wins"].tolist() == want and sum(want[:3]) == total                                          # win rule evaluate.py:155-160
+    assert g["summed"].size == 0 or g["summed"].tolist() == want                                          # (the all-reduced counts of the torch forms)
     assert g["rows_per_rank"].tolist() == [int(p["cnt"]) for p in parts] and str(g["collective"]) == "gather"
     assert sum(p["counts"] for p in parts).tolist() == want
     return parts, g
@@ -128,3 +159,18 @@ def test_one_rank_per_gpu_over_rccl_vs_oracle(tmp_path, oracle_mod):
     total = 8 * 65536 if world == 8 else world * 20000 + 3
     parts, g = _run_ranks(tmp_path, oracle_mod, "nccl", world=world, ndev=world, total=total)
     assert str(g["backend"]) == "nccl" and sorted(int(p["device"]) for p in parts) == list(range(world))
+
+
+def test_one_rank_over_the_abis_own_rccl_gather_vs_oracle(tmp_path, oracle_mod):
+    """evg_comm_unique_id / evg_comm_init / evg_gather_returns (RCCL opened by libevg.so itself, no torch.distributed) with a one-rank communicator"""
+    parts, g = _run_ranks(tmp_path, oracle_mod, "evg", world=1, ndev=1, total=4099)
+    assert str(g["backend"]) == "evg_gather_returns"
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs >= 2 GPUs: one rank per GPU over RCCL / xGMI (this box has %d)" % _gpus())
+def test_one_rank_per_gpu_over_the_abis_own_rccl_gather_vs_oracle(tmp_path, oracle_mod):
+    """the same through evg_gather_returns, one rank per visible GPU (at most 8): what a consumer without torch.distributed runs"""
+    world = min(_gpus(), 8)
+    total = 8 * 65536 if world == 8 else world * 20000 + 3
+    parts, g = _run_ranks(tmp_path, oracle_mod, "evg", world=world, ndev=world, total=total)
+    assert str(g["backend"]) == "evg_gather_returns" and sorted(int(p["device"]) for p in parts) == list(range(world))

@@ -607,6 +607,41 @@ def test_persistent_multi_turn_rollout_equals_stepwise(evg, oracle_mod, tpl):
     a.close()
 
 
+@pytest.mark.parametrize("N", [333, 65536 + 37])
+def test_single_turn_form_with_four_waves_per_workgroup_matches_oracle(evg, oracle_mod, N):
+    """Round-5 dispatch experiment (diagnostic library, lanes = 256): single-turn launches as 256-thread workgroups of four INDEPENDENT wavefronts (own LDS slice,
+    own 32 envs, no barrier) -- same results as the product's one-wavefront workgroups: caller-supplied orders, kernel-drawn orders and the scripted bots, with a
+    partial last workgroup (wavefronts beyond the last set leave at once)."""
+    seed = 77
+    oracle_mod.lib().evo_set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(lanes=256))
+    ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True)
+    assert np.array_equal(_np(env.reset()).astype(np.float64), ora.reset())
+    for t in range(12):
+        a = env.random_actions()
+        obs, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(_np(a))
+        assert np.array_equal(_np(obs).astype(np.float64), o_obs), ("obs", t)
+        assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(done), o_done)
+    env.rollout_random(165, turns_per_launch=1)                       # orders drawn in the kernel, one launch per turn, through an auto-reset
+    for t in range(165):
+        a = ora.random_actions()
+        o_obs, _, _, _ = ora.step(a)
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs) and np.array_equal(_np(env._actions), a)
+    check_state(env, ora.get_state(), "kernel-drawn orders")
+    env.rollout_policies(30, "cycle_rush_turn25", "swarm", fused=True, turns_per_launch=1)
+    pid = [evg.EvergladesVecEnv.POLICIES[s] for s in ("cycle_rush_turn25", "swarm")]
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(30):
+        ora.scripted_actions(pid[0], 0, o_obs, oa)
+        ora.scripted_actions(pid[1], 1, o_obs, oa)
+        o_obs, _, _, _ = ora.step(oa)
+    assert np.array_equal(_np(env.obs).astype(np.float64), o_obs)
+    check_state(env, ora.get_state(), "scripted")
+    assert np.array_equal(env.episode_stats()["totals"], ora.episode_stats()["totals"])
+    env.close()
+
+
 def test_16_envs_per_wave_variant_matches_oracle(evg, oracle_mod):
     """The step-kernel variant with 16 envs per wavefront (32 helper lanes join the balanced phases) is slower on MI355X and
     lives only in the diagnostic library (libevg_diag.so, evg_diag_configure): it must give the same results, single- and
@@ -844,6 +879,10 @@ def test_plain_c_client_of_the_abi(evg):
     o = _np(so).astype(np.int64).reshape(-1)
     assert (got["vs_episodes"], got["vs_p0"], got["vs_p1"], got["vs_tie"]) == tuple(int(x) for x in tot) and got["vs_episodes"] > got["episodes"]
     assert got["vs_obs_checksum"] == int((o * (1 + np.arange(o.size) % 7)).sum())
+    # ... and its third part: the path's one exchange through evg_comm_init / evg_gather_returns (RCCL opened by the library, a one-rank communicator here)
+    st = env.episode_stats()
+    assert got["gathered_rows"] == N and got["gathered_length_sum"] == int(st["length"].sum())
+    assert [got["gathered_p0"], got["gathered_p1"], got["gathered_tie"], got["gathered_unfinished"]] == [int((st["winner"] == k).sum()) for k in (0, 1, 2)] + [int((st["winner"] < 0).sum())]
     env.close()
 
 

@@ -35,8 +35,9 @@ def step_kernel(name, form):
     import re
     # evg_step_kernel<OT, 64, MULTI, MT, CHUNKED, SEAT>: the keyed-draw instantiations (MT = false) of the form's MULTI, plain or chunked; the learner form runs SEAT = true
     if form == "learner":
-        return re.search(r"evg_step_kernel<%s, 64, false, false, false, true>" % dtype, name) is not None
-    if re.search(r"evg_step_kernel<%s, 64, %s, false, (true|false), false>" % (dtype, multi), name):
+        return re.search(r"evg_step_kernel<%s, 64, false, false, false, true(, 1)?>" % dtype, name) is not None
+    # (round 5: a seventh template parameter, wavefronts per workgroup -- 1 in every product instantiation)
+    if re.search(r"evg_step_kernel<%s, 64, %s, false, (true|false), false(, 1)?>" % (dtype, multi), name):
         return True
     return "evg_step4_kernel<%s, %s" % (dtype, multi) in name
 

@@ -14,7 +14,7 @@ import csv, glob, json
 f = glob.glob("$OUT/stats/*/*_kernel_trace.csv")[0]
 rows = [(int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f))]
 rows.sort()
-pers = [(i, n, d) for i, n, d in rows if "evg_step_kernel<float, 64, true, false, false, false>" in n]
+pers = [(i, n, d) for i, n, d in rows if "evg_step_kernel<float, 64, true, false, false, false" in n]
 line = json.loads([l for l in open("$OUT/bench.json") if l.startswith("{")][-1])
 stats = open(glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]).read().splitlines()
 out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs"',

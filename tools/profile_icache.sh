@@ -12,7 +12,7 @@ for FORM in persistent perturn; do
 done
 python3 - <<PY
 import csv, glob
-for form, tail, tpl, nwin in (("persistent", "true, false>", 150, 1), ("perturn", "false, false>", 1, 150)):
+for form, tail, tpl, nwin in (("persistent", "true, false, false, false", 150, 1), ("perturn", "false, false, false, false", 1, 150)):
     f = glob.glob("$OUT/%s/*/*_counter_collection.csv" % form)[0]
     per = {}
     for r in csv.DictReader(open(f)):
