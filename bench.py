@@ -326,6 +326,8 @@ def main():
     ap.add_argument("--opponent", default="random", help="the on-device bot of the learner-seat leg (a name from everglades_amd._lib.POLICY_NAMES); random = the headline's game mix")
     ap.add_argument("--timing", default="torch", choices=["native", "torch"], help="single-rank timed region: launch duration from two pre-created torch events around an untimed call, one synchronisation in the closing bracket (default; 1.05-1.1 us per step of host time in the 20-step shape, "
                          "tools/driver_shape_timing_ab.sh) or from the native driver's own events, read inside the call, which synchronises itself (1.2-4.7 us)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "evg"], help="N > 1: the gather of episode results through torch.distributed (default; backend nccl = RCCL) or through the "
+                         "library's own RCCL entry points (evg_comm_init / evg_gather_returns: pack kernel + grouped send / receive on the launches' stream, no framework stream hop)")
     ap.add_argument("--repeats", type=int, default=0, help="how often the exact K-step region is timed (value = the median region); 0 = auto: 9 when K x the measured step time < 50 ms, else 1")
     ap.add_argument("--cache-mib", type=int, default=0, help="profiling runs: evg_config.cache_mib of the handle (the memory-side cache budget a chunked rollout launch may cycle through; 0 = the device's)")
     ap.add_argument("--pipeline", type=int, default=2, help="parts of the double-buffered leg (everglades_amd.PipelinedVecEnv)")
@@ -412,8 +414,19 @@ def main():
     played = 2 * PHASES                                        # turns since the first reset (pre-roll + settle)
     gather = evg.ResultGather(n_local, total, device, force=dist_on)   # preallocated buffers; rank 0 receives (one RCCL gather)
     win_counts_dev = torch.zeros(4, dtype=torch.int64, device=device)       # filled by the pack kernel: win bookkeeping of this rank's own rows
+    native = None
+    if dist_on and args.collective == "evg":
+        # RCCL through the C-ABI: the communicator's id goes from rank 0 to every rank over the process group that exists anyway
+        box = [evg.NativeGather.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, device=device if args.backend == "nccl" else None)
+        native = evg.NativeGather(env, total, world, rank, box[0])
+    def run_collective():
+        """the path's ONE exchange, enqueued on the launches' stream: rank 0 gets [total, 4], the others None"""
+        if native is not None:
+            return native()
+        return gather(env.packed_episode_results(out=gather.buffer))
     if dist_on:      # first use opens the RCCL channels of the gather: not part of the timed region
-        gather(env.packed_episode_results(out=gather.buffer))
+        run_collective()
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch, main_fused)
         played += args.warmup
@@ -461,7 +474,7 @@ def main():
             evs[rep][0].record()
             rollout(args.steps, False, args.turns_per_launch, main_fused)
             evs[rep][1].record()
-            gathered = gather(env.packed_episode_results(out=gather.buffer))
+            gathered = run_collective()
             evs[rep][2].record()
             torch.cuda.synchronize(device)
         regions.append([time.perf_counter() - t0, None, None])
@@ -761,6 +774,7 @@ def main():
                 ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None
             except Exception as ex:                       # reporting only
                 ver = "unavailable (%s)" % type(ex).__name__
+            rows_per_rank = gather.rows_per_rank(gathered) if native is None else [int((gathered[a:a + c, 2] >= 0).sum()) for a, c in zip([sum(native.counts[:r]) for r in range(world)], native.counts)]
             out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
                                   "collective": "one pack kernel + ONE torch.distributed.%s of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather), inside the timed region; the win-count self-check (all_reduce of 4 integers) runs after it" % gather.collective,
                                   "collective_us": max(p["collective_us"] for p in per_rank),
@@ -769,7 +783,7 @@ def main():
                                   "closing_bracket": "completion of the gather (rank 0 receives every rank's rows: it cannot end before the slowest rank's steps) + torch.cuda.synchronize(); per-rank times exchanged afterwards, max over ranks",
                                   "step_share_of_region": max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3 / (max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3 + max(p["collective_us"] for p in per_rank)),
                                   "expected": expected_if_wire_free(world, args.steps),
-                                  "collective_calls": gather.calls, "gathered_rows": int(gathered.shape[0]), "gathered_rows_with_a_finished_episode_per_rank": gather.rows_per_rank(gathered),
+                                  "collective_calls": gather.calls if native is None else repeats + 1, "collective_api": "torch.distributed" if native is None else "evg_gather_returns (RCCL through the C-ABI)", "gathered_rows": int(gathered.shape[0]), "gathered_rows_with_a_finished_episode_per_rank": rows_per_rank,
                                   "rows_expected_per_rank": gather.counts,
                                   "gathered_wins_equal_sum_of_per_rank_counts": True, "wins_p0_p1_tie_unfinished_sum_over_ranks": dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"],
                                   "per_rank": per_rank}

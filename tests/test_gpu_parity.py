@@ -861,7 +861,7 @@ def test_plain_c_client_of_the_abi(evg):
     N, turns, seed = 1000, 320, 77
     out = subprocess.run([exe, str(N), str(turns), str(seed)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    f = out.stdout.split()
+    f = " ".join(l for l in out.stdout.splitlines() if l.split(" ")[0] in ("envs", "vs_episodes", "gathered_rows")).split()      # (RCCL prints its version on stdout too)
     got = {f[i]: int(f[i + 1]) for i in range(0, len(f), 2)}
     env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
     env.reset()
