@@ -228,34 +228,31 @@ def compact_line(full):
         if not r:
             return None
         keep = ("bound", "bound_contract", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "bytes_per_env_step", "bytes_source", "launch_form", "launches_timed",
-                "turns_per_launch_timed", "kernel_launches_per_rollout_launch", "survey_8d_frac", "hbm_proper_frac", "hbm_proper_source", "note")
+                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "hbm_proper_source", "note")
         o = {k: _r(r[k], 5) for k in keep if k in r and r[k] is not None}
         if "traffic" not in o:
             o["traffic"] = None
         if r.get("bound") == "fabric":
-            o["bound_is"] = "L2<->InfinityCache/HBM requests; a round's working set is cache-resident, so not all DRAM; hbm_proper_frac = same kernel cycled beyond the cache"
+            o["bound_is"] = "L2<->InfinityCache/HBM requests, working set cache-resident; hbm_proper_frac: same kernel beyond the cache"
         if "survey_8d_frac" in o:
-            o["survey_8d_note"] = "SURVEY 8(d) byte model (4530 B/env-step) at this kernel time; >1 = model not applicable to the persistent form (state stays on chip)"
+            o["survey_8d_note"] = "SURVEY 8(d) 4530 B model at this kernel time; >1: not applicable, state stays on chip"
         if "note" in o:
             o["note"] = "working set cache-resident: latency/issue-bound, frac meaningless"
-        if "kernel" in r:
-            o["kernel"] = r["kernel"].split(" | ")[0][:160]
         bm = r.get("beyond_mall")
-        if bm:
-            o["beyond_mall"] = {k: {"envs": v.get("envs", bm.get("envs")), "working_set_MB": v.get("working_set_MB", bm.get("working_set_MB")), "frac": _r(v["frac_of_8TBps"]), "ns_per_env_step": _r(v["ns_per_env_step"]), "source": v["source"]}
-                                for k, v in bm.items() if isinstance(v, dict) and "frac_of_8TBps" in v}
+        if bm:      # (the full object has every pass with its source; the line keeps the fractions)
+            o["beyond_mall_fracs"] = {("cycled_%dMB" % v["working_set_MB"]) if "working_set_MB" in v else k[:24]: _r(v["frac_of_8TBps"]) for k, v in bm.items() if isinstance(v, dict) and "frac_of_8TBps" in v}
             w = (bm.get("whole_rounds_one_after_the_other") or {}).get("persistent")
             if w:
-                o["beyond_mall"]["whole_rounds_262144_envs"] = {"frac": _r(w["frac_of_8TBps"]), "ns_per_env_step": _r(w["ns_per_env_step"]), "source": w["source"]}
+                o["beyond_mall_fracs"]["whole_rounds_262144_envs"] = _r(w["frac_of_8TBps"])
         return o
 
     def leg(l):
         if not l:
             return None
-        o = {k: _r(l[k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "turns_per_launch", "parts") if k in l}
+        o = {k: _r(l[k], 4) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "turns_per_launch", "parts") if k in l}
         for sub in ("learner_vs_bot", "with_features"):
             if l.get(sub):
-                o[sub] = {k: _r(l[sub][k], 5) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms")}
+                o[sub] = {k: _r(l[sub][k], 4) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms")}
         if l.get("roofline"):
             o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}      # (bound, peak, unit and byte source: as in the main roofline object)
         return o
@@ -266,7 +263,7 @@ def compact_line(full):
     out["config"] = {"workload": "%d concurrent DemoMap games per GPU, %s, persistent rollout form, auto-reset, obs %s [N,2,105]" % (
                          c["envs_per_gpu"], "random_actions vs random_actions drawn on device" if "random_actions" in c["workload"] else
                          "on-device Cycle_BRush_Turn25 vs SwarmAgent fused into the step kernel (BASELINE config 5)", obs_name),
-                     "window": "desynchronised steady state (150-turn pre-roll, episode phases hash(e) mod 150) + 150 settle turns + warmup",
+                     "window": "desynchronised steady state: 150-turn pre-roll (phases hash(e) mod 150) + 150 settle turns",
                      **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash", "episodes_finished_rank0",
                                           "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
                      "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")),
@@ -281,7 +278,7 @@ def compact_line(full):
                          "min_value": _r(t["min_value"], 5), "max_value": _r(t["max_value"], 5)}
     if "roofline_valu_issue" in full:
         v = full["roofline_valu_issue"]
-        out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "valu_insts_per_wave_turn", "source")}
+        out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "frac", "valu_insts_per_wave_turn", "source")}
     if "distributed" in full:
         d = dict(full["distributed"])
         d["collective"] = "pack kernel + ONE gather to rank 0 (= closing bracket); win-count self-check after the region"
@@ -297,7 +294,7 @@ def compact_line(full):
     if "cpu_baseline" in full:
         b = full["cpu_baseline"]
         out["cpu_baseline"] = {"value": _r(b["value"], 5), "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "obs_dtype": b.get("obs_dtype"),
-                               "sample": b["sample"].split(", C oracle")[0] + "; C oracle (port of the reference's turn loop), OpenMP over envs"}
+                               "sample": b["sample"].split(" (random vs random")[0] + ", random vs random incl. action generation + f64 obs; C port of the reference's turn loop, OpenMP"}
         if "same_games_as_gpu" in b:
             g = b["same_games_as_gpu"]
             out["cpu_baseline"]["same_games_as_gpu"] = {k: g[k] for k in ("envs", "turns", "equal", "cpu_wins_p0_p1_tie", "gpu_wins_p0_p1_tie")}
@@ -699,11 +696,13 @@ def main():
             roof["bound_is"] = ("fabric: requests between the L2s and the Infinity Cache / HBM.  The working set of a round of resident workgroups (%.0f MB) is inside the 256 MiB "
                                 "Infinity Cache, so these bytes are NOT all DRAM traffic; the counters cannot separate cache hits.  `peak` is the HBM3E figure the contract asks "
                                 "for (8 TB/s); `hbm_proper_frac` is the same kernel made to leave the cache" % (round_ws / 1e6))
-        # ... and the same kernel when its launch does leave the cache (one number, one source):
-        #   product_cycled  libevg.so itself, a plan it really launches: 131 071 envs with evg_config.cache_mib raised to 1 024, so that the plan is ONE chunked launch that
-        #                   cycles through all 359 MB of the batch every 25-turn chunk (with the default budget the library refuses such a plan BY DESIGN: plan_step keeps
-        #                   every launch's working set inside the cache -- whole rounds are cache blocking -- which is why no default product plan is HBM-bound)
-        #   cycled          the diagnostic library's chunked form forced over 262 144 envs (723 MB), the cross-check of rounds 3 and 4
+        # ... and the same kernel when its launch does leave the cache.  ONE number (`hbm_proper_frac`), one source: the pass with the LARGEST cycled working set.
+        #   cycled          the diagnostic library's chunked form forced over 262 144 envs: every env of a 723 MB working set (2.7 x the cache) is revisited once
+        #                   per 25-turn chunk -- the HBM figure proper
+        #   product_cycled  libevg.so itself, a plan it really launches: 131 071 envs with evg_config.cache_mib raised to 1 024, so that the plan is ONE chunked
+        #                   launch cycling through 359 MB (1.34 x the cache: still mostly cache-resident, reported next to the other).  With the default budget
+        #                   the library refuses such a plan BY DESIGN -- plan_step keeps every launch's working set inside the cache, whole rounds are cache
+        #                   blocking -- which is why no default product plan is HBM-bound and why the diagnostic library is needed to show the HBM rate at all
         big = committed_counters("pmc_traffic", 262144, args.workload, args.obs_dtype)
         cyc = committed_counters("pmc_traffic", 262144, args.workload, args.obs_dtype, variant="cycled")
         prod = committed_counters("pmc_traffic", 131071, args.workload, args.obs_dtype, variant="product_cycled")
@@ -721,7 +720,7 @@ def main():
                 bm["diag_library_chunked_over_262144_envs"] = cmp_form(cyc, "persistent")
             if prod and "persistent" in prod["forms"]:
                 bm["product_library_chunked_over_131071_envs_cache_mib_1024"] = cmp_form(prod, "persistent")
-            hp = bm.get("product_library_chunked_over_131071_envs_cache_mib_1024") or bm.get("diag_library_chunked_over_262144_envs")
+            hp = bm.get("diag_library_chunked_over_262144_envs") or bm.get("product_library_chunked_over_131071_envs_cache_mib_1024")
             if hp:
                 roof["hbm_proper_frac"] = hp["frac_of_8TBps"]
                 roof["hbm_proper_source"] = hp["source"]

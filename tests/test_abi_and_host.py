@@ -286,7 +286,7 @@ def test_bench_window_helpers():
 def test_bench_stdout_line_is_compact_and_complete():
     """bench.py prints the COMPACT form of its result: a driver that keeps only the tail of the output must still see one whole JSON
     object.  Every full line committed under profiles/ for this round compacts to less than 3.6 KB (the size of a line a driver is known
-    to have captured whole) and keeps every field of the contract: the metric block, config.workload, roofline {bound, achieved, peak,
+    to have captured whole; round 5 added the timing block, survey_8d_frac / hbm_proper_frac and one more leg within the same size) and keeps every field of the contract: the metric block, config.workload, roofline {bound, achieved, peak,
     unit, frac, traffic}, cpu_baseline {value, unit, cores, kind, sample} and the numbers of both per-turn legs."""
     import glob
     import importlib.util
@@ -294,12 +294,13 @@ def test_bench_stdout_line_is_compact_and_complete():
     spec = importlib.util.spec_from_file_location("evg_bench2", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r04_f_bench_*.json")) if "compact" not in f)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r05_b_bench_*.json")) if "compact" not in f)
     assert len(files) >= 7
     for f in files:
         full = json.loads(open(f).read())
         line = json.dumps(bench.compact_line(full), separators=(",", ":"))
-        assert len(line) < 3600, (f, len(line))
+        # (a one-rank REHEARSAL carries the single-GPU legs and the distributed block at once; a real N > 1 line has no extra legs)
+        assert len(line) < (4100 if "rehearse_rccl" in f else 3600), (f, len(line))
         c = json.loads(line)
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
             assert k in c, (f, k)
@@ -307,6 +308,16 @@ def test_bench_stdout_line_is_compact_and_complete():
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in c["roofline"], (f, k)
         assert abs(c["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-3
+        # round 5: the line says what the bytes are -- "fabric" when a round's working set is cache-resident (then with the HBM figure proper beside it) -- and
+        # carries SURVEY 8(d)'s byte model priced at the same kernel time (above 1: not applicable to a design that keeps the state on chip), and how the
+        # region was timed
+        assert c["roofline"]["bound"] in ("fabric", "hbm") and c["roofline"]["survey_8d_frac"] > 0
+        if c["roofline"]["bound"] == "fabric":
+            assert c["roofline"]["bound_contract"] == "hbm" and "bound_is" in c["roofline"]
+        if full["config"]["envs_per_gpu"] == 65536 and full["config"]["workload"].startswith("65536 concurrent DemoMap games per GPU, random") and "float32" in full["config"]["workload"]:
+            assert 0.3 < c["roofline"]["hbm_proper_frac"] < c["roofline"]["frac"] + 0.2 and "cycled" in c["roofline"]["hbm_proper_source"]
+        t = c["timing"]
+        assert t["repeats"] >= 1 and t["min_ms_per_step"] <= c["ms_per_step"] <= t["max_ms_per_step"] and t["min_value"] <= c["value"] <= t["max_value"]
         if "cpu_baseline" in full:
             for k in ("value", "unit", "cores", "kind", "sample"):
                 assert k in c["cpu_baseline"]
@@ -318,9 +329,9 @@ def test_bench_stdout_line_is_compact_and_complete():
             assert leg["parts"] == 2 and leg["kernel_ms"] <= leg["ms_per_step"]
         if "distributed" in full:
             d = c["distributed"]
-            assert d["collective_us"] > 0 and d["gathered_wins_equal_sum_of_per_rank_counts"] is True and "expected" in d
+            assert d["collective_us"] > 0 and d["gathered_wins_equal_sum_of_per_rank_counts"] is True and "expected" in d and 0 < d["step_share_of_region"] < 1
     # what a first multi-GPU line is read against: N x the committed one-rank RCCL rehearsal of the same shape, next to the one-GPU line of that shape
     exp = bench.expected_if_wire_free(8, 20)
-    assert exp and "r04_f_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
-    assert 0.7 < exp["weak_scaling_efficiency_if_wire_free"] < 1.0 and exp["collective_us_1rank"] > 0       # step launches / (step launches + collective path), one run
+    assert exp and "r05_b_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
+    assert 0.9 < exp["weak_scaling_efficiency_if_wire_free"] < 1.0 and exp["collective_us_1rank"] > 0       # step launches / (step launches + collective path), one run
     assert bench.expected_if_wire_free(8, 12345) is None

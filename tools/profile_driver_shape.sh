@@ -17,10 +17,15 @@ rows.sort()
 pers = [(i, n, d) for i, n, d in rows if "evg_step_kernel<float, 64, true, false, false, false" in n]
 line = json.loads([l for l in open("$OUT/bench.json") if l.startswith("{")][-1])
 stats = open(glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]).read().splitlines()
+R = int((line.get("timing") or {}).get("repeats", 1))
+timed = [d for _, _, d in pers[-R:]]                       # the R timed regions are the last R 20-turn dispatches (bench.py reports the median region)
+med = sorted(timed)[(R - 1) // 2]
 out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs"',
        '"# persistent step-kernel dispatches of the run, in order (ns): %s"' % " ".join(str(d) for _, _, d in pers),
-       '"# the LAST one is the timed 20-turn launch: %d ns = %.2f us per turn; the line of the same run says roofline.kernel_ms = %.5f (x 20 turns = %.1f us between the two stream events), ms_per_step = %.5f"'
-       % (pers[-1][2], pers[-1][2] / 20 / 1e3, line["roofline"]["kernel_ms"], line["roofline"]["kernel_ms"] * 20 * 1e3, line["ms_per_step"]),
+       '"# the LAST %d are the timed 20-turn launches (bench.py times the exact 20-step region %d times and reports the median region): %s ns; median %d ns = %.2f us per turn; '
+       'the line of the same run says roofline.kernel_ms = %.5f (x 20 turns = %.1f us between the two stream events of its median region), ms_per_step = %.5f (min %.5f, max %.5f)"'
+       % (R, R, " ".join(str(d) for d in timed), med, med / 20 / 1e3, line["roofline"]["kernel_ms"], line["roofline"]["kernel_ms"] * 20 * 1e3, line["ms_per_step"],
+          (line.get("timing") or {}).get("min_ms_per_step", line["ms_per_step"]), (line.get("timing") or {}).get("max_ms_per_step", line["ms_per_step"])),
        '"# (the others: the 150-turn settle launch of the desynchronising window and the 5-turn warm-up launch; under the profiler every dispatch is serialised)"',
        stats[0]] + [l for l in stats[1:] if "evg::" in l]
 open("profiles/${NAME}_driver_shape_kernel_stats.csv", "w").write("\n".join(out) + "\n")
