@@ -59,6 +59,7 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0   # 1024 SIMDs x 2.4 GHz / 4 
                                                      # waves on this kernel's instruction mix (tools/micro/inst_rate.hip, profiles/r02_q_*: 4.3-4.8 cycles per
                                                      # instruction per SIMD for mul / f64 / bfe / perm / cndmask / DPP, 2.7 for plain add / xor; the guide's
                                                      # 2-cycle SIMD-32 issue holds for the simplest ops only).  SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction.
+NOMINAL_MS_PER_STEP = 0.02   # for the repeat rule of the timed region only (one rule for every rank, box and batch size)
 PHASES = 150                 # episode length of random vs random (server.py:321): the pre-roll spreads phases over it
 
 
@@ -325,7 +326,7 @@ def main():
                          "tools/driver_shape_timing_ab.sh) or from the native driver's own events, read inside the call, which synchronises itself (1.2-4.7 us)")
     ap.add_argument("--collective", default="torch", choices=["torch", "evg"], help="N > 1: the gather of episode results through torch.distributed (default; backend nccl = RCCL) or through the "
                          "library's own RCCL entry points (evg_comm_init / evg_gather_returns: pack kernel + grouped send / receive on the launches' stream, no framework stream hop)")
-    ap.add_argument("--repeats", type=int, default=0, help="how often the exact K-step region is timed (value = the median region); 0 = auto: 9 when K x the measured step time < 50 ms, else 1")
+    ap.add_argument("--repeats", type=int, default=0, help="how often the exact K-step region is timed (value = the median region); 0 = auto: 9 when K x a nominal 0.02 ms < 50 ms (K <= 2500), else 1")
     ap.add_argument("--cache-mib", type=int, default=0, help="profiling runs: evg_config.cache_mib of the handle (the memory-side cache budget a chunked rollout launch may cycle through; 0 = the device's)")
     ap.add_argument("--pipeline", type=int, default=2, help="parts of the double-buffered leg (everglades_amd.PipelinedVecEnv)")
     ap.add_argument("--details", default="", help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
@@ -432,11 +433,12 @@ def main():
         rollout(args.steps, False, args.turns_per_launch, True, prepare=True)     # capture + instantiate the graphs of the K-step launch shape now (nothing is played)
 
     # ---- how often the exact K-step region is timed.  A region of a few hundred microseconds (the driver's --steps 20: 0.4 ms) is ONE draw from a
-    # distribution whose box-to-box and run-to-run spread is +-8 %: when K x (the step time the settle launches just showed) is below 50 ms the region is
+    # distribution whose box-to-box and run-to-run spread is +-8 %: when K x a nominal 20 us per step is below 50 ms the region is
     # repeated R = 9 times -- each repeat bracketed exactly like the single region (barrier + synchronize on both sides, nothing else inside) -- and
     # value / ms_per_step come from the MEDIAN region; min and max are reported next to it.  --repeats N forces N (profiling runs: 1).
-    est_ms_per_step = settle_ms / PHASES if settle_ms > 0 else 0.02
-    repeats = args.repeats if args.repeats > 0 else (9 if args.steps * est_ms_per_step < 50.0 else 1)
+    # (the rule must give the SAME answer on every rank -- a rank that timed one region more would wait in a barrier nobody else enters -- so it uses a nominal
+    # 20 us per step, not this rank's own measurement: K <= 2 500 steps are repeated)
+    repeats = args.repeats if args.repeats > 0 else (9 if args.steps * NOMINAL_MS_PER_STEP < 50.0 else 1)
     use_events = dist_on or args.timing == "torch"
     if use_events:      # torch creates an event at its first record(): not inside the timed region
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(repeats)]
@@ -505,7 +507,7 @@ def main():
                      "collective_us": float(allr[r, med, 2])} for r in range(world)]
     timing = {"repeats": repeats, "reported": "median region", "region_ms": [x * 1e3 for x in region_s], "min_ms_per_step": min(region_s) / args.steps * 1e3,
               "max_ms_per_step": max(region_s) / args.steps * 1e3, "min_value": total * args.steps / max(region_s), "max_value": total * args.steps / min(region_s),
-              "rule": "R = 9 when K x the settle launches' ms per step < 50 ms, else 1 (--repeats N forces N); every region = exactly K steps between barrier + synchronize brackets"}
+              "rule": "R = 9 when K x 0.02 ms (nominal) < 50 ms, else 1 (--repeats N forces N); every region = exactly K steps between barrier + synchronize brackets"}
     step_kernel_ms = kernel_ms_sum / args.steps
     st = env.episode_stats()
     if not dist_on:
