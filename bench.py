@@ -229,7 +229,7 @@ def compact_line(full):
         if not r:
             return None
         keep = ("bound", "bound_contract", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "bytes_per_env_step", "bytes_source", "launch_form", "launches_timed",
-                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "hbm_proper_source", "note")
+                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "hbm_proper_source", "algorithmic_bytes_per_env_step", "traffic_over_algorithmic", "note")
         o = {k: _r(r[k], 5) for k in keep if k in r and r[k] is not None}
         if "traffic" not in o:
             o["traffic"] = None
@@ -659,6 +659,13 @@ def main():
                           "bytes_per_env_step": bpe, "bytes_source": pmc["_file"] + " [%s]" % form_key,
                           "kernel_us_rocprof": form.get("kernel_us_per_turn"), "frac_at_rocprof_kernel_time": form.get("frac_of_8TBps"),
                           "ratio_to_mandatory_outputs": bpe / mand})
+                # this DESIGN's algorithmic bytes: the outputs a turn must write + every health row combat hit, read once and written once --
+                # the rows written are what WRITE_SIZE shows beyond the outputs (persistent form; single-turn forms also move the state words: in `mand`-free terms
+                # their figure is an upper bound).  traffic / algorithmic > 1 is over-fetch: whole 128-byte lines for 64-byte rows, straddling rows
+                if form.get("WRITE_SIZE_KB_mean") and form_key == "persistent":
+                    rows_written = max(0.0, form["WRITE_SIZE_KB_mean"] * 1024.0 / form["turns_per_launch"] / n_local - mand)
+                    r["algorithmic_bytes_per_env_step"] = mand + 2.0 * rows_written
+                    r["traffic_over_algorithmic"] = bpe / (mand + 2.0 * rows_written)
             else:
                 achieved = mand * n_local / (kernel_ms * 1e-3) / 1e9
                 r.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": mand,
