@@ -214,6 +214,18 @@ def expected_if_wire_free(world, steps):
     return out
 
 
+def repeats_for(steps, forced=0):
+    """How often the exact K-step region is timed: `forced` when given, else 9 when K x a nominal 0.02 ms < 50 ms (K <= 2 500) and 1 otherwise.  The rule
+    depends on nothing a rank measures, so every rank of a multi-GPU job times the same number of regions."""
+    return forced if forced > 0 else (9 if steps * NOMINAL_MS_PER_STEP < 50.0 else 1)
+
+
+def median_region(region_s):
+    """index of the median timed region (the lower of the two middle ones for an even count): what `value` and `ms_per_step` are reported from"""
+    order = sorted(range(len(region_s)), key=lambda i: region_s[i])
+    return order[(len(region_s) - 1) // 2]
+
+
 def _r(x, n=4):
     """numbers of the compact line: n significant digits"""
     if isinstance(x, float):
@@ -438,7 +450,7 @@ def main():
     # value / ms_per_step come from the MEDIAN region; min and max are reported next to it.  --repeats N forces N (profiling runs: 1).
     # (the rule must give the SAME answer on every rank -- a rank that timed one region more would wait in a barrier nobody else enters -- so it uses a nominal
     # 20 us per step, not this rank's own measurement: K <= 2 500 steps are repeated)
-    repeats = args.repeats if args.repeats > 0 else (9 if args.steps * NOMINAL_MS_PER_STEP < 50.0 else 1)
+    repeats = repeats_for(args.steps, args.repeats)
     use_events = dist_on or args.timing == "torch"
     if use_events:      # torch creates an event at its first record(): not inside the timed region
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(repeats)]
@@ -497,8 +509,7 @@ def main():
         region_s = allr[:, :, 0].max(dim=0).values.tolist()
     else:
         region_s = [r[0] for r in regions]
-    order = sorted(range(repeats), key=lambda i: region_s[i])
-    med = order[(repeats - 1) // 2]                                      # the median region (the lower one of the two middle ones for an even count)
+    med = median_region(region_s)
     dt = region_s[med]
     kernel_ms_sum = regions[med][1]
     collective_ms = regions[med][2]

@@ -283,6 +283,20 @@ def test_bench_window_helpers():
                 assert 1000 < d["kernels"]["persistent"]["valu_insts_per_wave_turn"] < 10000
 
 
+def test_bench_times_the_region_several_times_and_reports_the_median():
+    """bench.py times the exact K-step region R times and reports the median region (round 5: a 0.4 ms region is one draw from a +-8 % distribution).  The rule
+    for R depends on K only -- every rank of a multi-GPU job must time the same number of regions -- and the median is the lower middle one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("evg_bench3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.repeats_for(20) == 9 and bench.repeats_for(450) == 9 and bench.repeats_for(2499) == 9 and bench.repeats_for(2500) == 1 and bench.repeats_for(100000) == 1
+    assert bench.repeats_for(20, forced=1) == 1 and bench.repeats_for(100000, forced=3) == 3
+    assert bench.median_region([5.0]) == 0
+    assert bench.median_region([0.41, 0.37, 0.36, 0.39, 0.36, 0.35, 0.40, 0.38, 0.42]) == 7        # 0.38: four regions below, four above
+    assert bench.median_region([3.0, 1.0, 2.0, 4.0]) == 2                                              # even count: the lower middle one
+
+
 def test_bench_stdout_line_is_compact_and_complete():
     """bench.py prints the COMPACT form of its result: a driver that keeps only the tail of the output must still see one whole JSON
     object.  Every full line committed under profiles/ for this round compacts to less than 3.6 KB (the size of a line a driver is known
