@@ -329,7 +329,9 @@ def test_bench_stdout_line_is_compact_and_complete():
         if c["roofline"]["bound"] == "fabric":
             assert c["roofline"]["bound_contract"] == "hbm" and "bound_is" in c["roofline"]
         if full["config"]["envs_per_gpu"] == 65536 and full["config"]["workload"].startswith("65536 concurrent DemoMap games per GPU, random") and "float32" in full["config"]["workload"]:
-            assert 0.3 < c["roofline"]["hbm_proper_frac"] < c["roofline"]["frac"] + 0.2 and "cycled" in c["roofline"]["hbm_proper_source"]
+            assert 0.3 < c["roofline"]["hbm_proper_frac"] < 0.9 and "cycled" in c["roofline"]["hbm_proper_source"]
+            if "rehearse" not in f:                                   # (two gloo ranks share one GPU: that line's own fraction says nothing)
+                assert c["roofline"]["hbm_proper_frac"] < c["roofline"]["frac"] + 0.05      # leaving the cache does not make the kernel faster
         t = c["timing"]
         assert t["repeats"] >= 1 and t["min_ms_per_step"] <= c["ms_per_step"] <= t["max_ms_per_step"] and t["min_value"] <= c["value"] <= t["max_value"]
         if "cpu_baseline" in full:
