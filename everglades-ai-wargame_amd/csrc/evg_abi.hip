@@ -1243,7 +1243,8 @@ int evg_gather_returns(evg_handle* h, int root, float* recv_out, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!h->comm) return fail(EVG_ERR_INVALID, "gather_returns: no communicator (evg_comm_init)");
     if (root < 0 || root >= h->comm_world) return fail(EVG_ERR_INVALID, "gather_returns: root %d of %d ranks", root, h->comm_world);
-    if ((h->comm_rank == root) != (recv_out != nullptr)) return fail(EVG_ERR_INVALID, "gather_returns: recv_out is required on the root rank and must be NULL elsewhere");
+    if ((h->comm_rank == root) != (recv_out != nullptr))
+        return fail(EVG_ERR_INVALID, "gather_returns: recv_out is required on the root rank and must be NULL elsewhere");
     EVG_NEED_ALIGNED16(recv_out);
     const RcclApi* R = rccl();
     if (!R) return fail(EVG_ERR_COMM, "RCCL is not available: %s", g_rccl.why.c_str());

@@ -395,7 +395,8 @@ int launch_smart_state(const DevState& S, int player, const void* obs, int seat_
 }
 
 // network output -> orders: one DPP row (16 lanes) per env
-int launch_smart_actions(const DevState& S, int player, const void* obs, int seat_only, const float* q, int32_t* actions, int32_t* directions, int obs_dtype, void* stream) {
+int launch_smart_actions(const DevState& S, int player, const void* obs, int seat_only, const float* q, int32_t* actions, int32_t* directions, int obs_dtype,
+                         void* stream) {
     const dim3 grid((unsigned)(((size_t)S.N * 16 + 255) / 256)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int2* a = reinterpret_cast<int2*>(actions);
