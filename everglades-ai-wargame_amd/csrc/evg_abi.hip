@@ -486,6 +486,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     S.auto_reset = cfg->auto_reset ? 1 : 0;
     S.seed_lo = (uint32_t)cfg->seed;
     S.seed_hi = (uint32_t)(cfg->seed >> 32);
+    for (int r = 0; r < 10; ++r) { S.keys.k[2 * r] = S.seed_lo + (uint32_t)r * PHILOX_W0; S.keys.k[2 * r + 1] = S.seed_hi + (uint32_t)r * PHILOX_W1; }
     S.env_id_base = (uint32_t)cfg->env_id_base;
     rc = dev_alloc(h, &S.grp, 24 * N);
     if (!rc) rc = dev_alloc(h, &S.stamp, 6 * N);

@@ -23,6 +23,7 @@
 #pragma once
 #include <stdint.h>
 #include "../../include/evg.h"
+#include "evg_rng.h"
 
 namespace evg {
 
@@ -101,6 +102,7 @@ struct DevState {
     uint32_t* mt_key;            // [624][N] stock-entropy mode only (evg_mt.h), else NULL
     uint32_t* mt_pos;            // [N]
     uint32_t  seed_lo, seed_hi, env_id_base;
+    PhiloxKeys keys;             // the ten round keys of every Philox block of this handle (evg_rng.h), from the seed
     const DevTables* T;
     uint32_t* progress;          // [ceil(N / 32)] chunked persistent launches: set s of 32 envs has finished chunk c of the launch <=> progress[s] == c + 1
     uint32_t* queue;             // [1024] chunked launches: next unit of each XCD's queue, one counter per 256-byte line.  queue and progress are ONE
