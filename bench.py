@@ -14,8 +14,14 @@ episode phases of the batch -- and of the 32 envs of every wavefront -- are spre
 every timed turn sees the episode-average mix of early (few fights) and late (many fights) positions, with
 ~1/150 of the envs resetting per turn.  The MIX of positions is therefore the same for any K; the launch shape is not:
 the K timed turns are ceil(K / 150) launches of the persistent step kernel, and a launch lasts as long as its slowest
-wavefront plus a start-up and a host synchronisation, which weigh more on a 20-turn launch (--steps 20: 19-20 us per
-step) than on 150-turn ones (the default --steps 450: 16-17 us per step).  Both shapes are kept under profiles/.
+wavefront plus a start-up and a host synchronisation, which weigh more on a 20-turn launch (--steps 20: about 16 us per
+step) than on 150-turn ones (the default --steps 450: about 14 us per step).  Both shapes are kept under profiles/.
+
+Clock.  The kernel's time is a constant number of shader CYCLES, and the shader clock of a GPU that has just started working
+needs 30-40 ms of load to reach the value it then sustains (1.9-2.1 -> 2.35 GHz: profiles/r05_d_default_run_kernel_stats.csv).
+So that the timed regions measure the rollout rate and not the governor's ramp, a scratch handle of the same size plays untimed
+rollouts for --clock-warmup-ms (default 80) right before the W warm-up steps; the line reports it (timing.clock_warmup_ms), and
+--clock-warmup-ms 0 gives the cold figure.
 
 Besides the headline (persistent rollout form) the line carries, under config, three legs that pay one step launch per turn --
 what a Gym consumer gets from env.step(): `one_launch_per_turn` (orders drawn inside the step kernel),
@@ -288,7 +294,7 @@ def compact_line(full):
     if "timing" in full:
         t = full["timing"]
         out["timing"] = {"repeats": t["repeats"], "reported": t["reported"], "min_ms_per_step": _r(t["min_ms_per_step"], 5), "max_ms_per_step": _r(t["max_ms_per_step"], 5),
-                         "min_value": _r(t["min_value"], 5), "max_value": _r(t["max_value"], 5)}
+                         "min_value": _r(t["min_value"], 5), "max_value": _r(t["max_value"], 5), "clock_warmup_ms": _r(t.get("clock_warmup", {}).get("ms", 0.0), 3)}
     if "roofline_valu_issue" in full:
         v = full["roofline_valu_issue"]
         out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "frac", "valu_insts_per_wave_turn", "source")}
@@ -339,6 +345,8 @@ def main():
     ap.add_argument("--collective", default="torch", choices=["torch", "evg"], help="N > 1: the gather of episode results through torch.distributed (default; backend nccl = RCCL) or through the "
                          "library's own RCCL entry points (evg_comm_init / evg_gather_returns: pack kernel + grouped send / receive on the launches' stream, no framework stream hop)")
     ap.add_argument("--repeats", type=int, default=0, help="how often the exact K-step region is timed (value = the median region); 0 = auto: 9 when K x a nominal 0.02 ms < 50 ms (K <= 2500), else 1")
+    ap.add_argument("--clock-warmup-ms", type=float, default=80.0, help="untimed: a SCRATCH handle of the same size plays rollouts for this long right before the --warmup steps, so that the "
+                    "timed regions run at the shader clock a long rollout sustains (the governor needs 30-40 ms of load to get there: profiles/r05_d_default_run_kernel_stats.csv); 0 = off")
     ap.add_argument("--cache-mib", type=int, default=0, help="profiling runs: evg_config.cache_mib of the handle (the memory-side cache budget a chunked rollout launch may cycle through; 0 = the device's)")
     ap.add_argument("--pipeline", type=int, default=2, help="parts of the double-buffered leg (everglades_amd.PipelinedVecEnv)")
     ap.add_argument("--details", default="", help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
@@ -437,12 +445,30 @@ def main():
         return gather(env.packed_episode_results(out=gather.buffer))
     if dist_on:      # first use opens the RCCL channels of the gather: not part of the timed region
         run_collective()
+    if main_fused is True:
+        rollout(args.steps, False, args.turns_per_launch, True, prepare=True)     # capture + instantiate the graphs of the K-step launch shape now (nothing is played)
+
+    # ---- clock warm-up (untimed, not part of the measured games).  The shader clock of an MI355X that has just started working climbs from ~1.9-2.1 GHz to the
+    # ~2.35 GHz it then sustains over the first 30-40 ms of load, and this kernel's time is a constant number of CYCLES (33 k per turn at 65 536 envs: the
+    # dispatch list with GRBM_GUI_ACTIVE in profiles/r05_d_default_run_kernel_stats.csv) -- so a region timed 10 ms after the start of the process (the driver's
+    # --steps 20 --warmup 5) used to measure the governor's ramp, 14 % below what every later millisecond of a rollout gets.  A scratch handle of the same size
+    # plays 150-turn rollouts for --clock-warmup-ms right before the W warm-up steps; the measured handle, its games and the W / K contract are untouched.
+    clock_warmup = {"requested_ms": args.clock_warmup_ms, "ms": 0.0, "turns": 0}
+    if args.clock_warmup_ms > 0:
+        scratch = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed + 1, env_id_base=first, obs_dtype=args.obs_dtype, auto_reset=True, library=args.library)
+        scratch.reset()
+        torch.cuda.synchronize(device)
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < args.clock_warmup_ms:
+            scratch.rollout_random(PHASES, turns_per_launch=PHASES)
+            torch.cuda.synchronize(device)
+            clock_warmup["turns"] += PHASES
+        clock_warmup["ms"] = (time.perf_counter() - t_w) * 1e3
+        scratch.close()
+        del scratch
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch, main_fused)
         played += args.warmup
-
-    if main_fused is True:
-        rollout(args.steps, False, args.turns_per_launch, True, prepare=True)     # capture + instantiate the graphs of the K-step launch shape now (nothing is played)
 
     # ---- how often the exact K-step region is timed.  A region of a few hundred microseconds (the driver's --steps 20: 0.4 ms) is ONE draw from a
     # distribution whose box-to-box and run-to-run spread is +-8 %: when K x a nominal 20 us per step is below 50 ms the region is
@@ -518,7 +544,9 @@ def main():
                      "collective_us": float(allr[r, med, 2])} for r in range(world)]
     timing = {"repeats": repeats, "reported": "median region", "region_ms": [x * 1e3 for x in region_s], "min_ms_per_step": min(region_s) / args.steps * 1e3,
               "max_ms_per_step": max(region_s) / args.steps * 1e3, "min_value": total * args.steps / max(region_s), "max_value": total * args.steps / min(region_s),
-              "rule": "R = 9 when K x 0.02 ms (nominal) < 50 ms, else 1 (--repeats N forces N); every region = exactly K steps between barrier + synchronize brackets"}
+              "rule": "R = 9 when K x 0.02 ms (nominal) < 50 ms, else 1 (--repeats N forces N); every region = exactly K steps between barrier + synchronize brackets",
+              "clock_warmup": dict(clock_warmup, note="untimed rollouts of a SCRATCH handle right before the W warm-up steps: the timed regions run at the shader clock a long "
+                                                      "rollout sustains instead of inside the governor's ramp of the first 30-40 ms (--clock-warmup-ms 0 = off)")}
     step_kernel_ms = kernel_ms_sum / args.steps
     st = env.episode_stats()
     if not dist_on:

@@ -308,7 +308,7 @@ def test_bench_stdout_line_is_compact_and_complete():
     spec = importlib.util.spec_from_file_location("evg_bench2", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r05_c_bench_*.json")) if "compact" not in f)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r05_d_bench_*.json")) if "compact" not in f)
     assert len(files) >= 7
     for f in files:
         full = json.loads(open(f).read())
@@ -348,6 +348,6 @@ def test_bench_stdout_line_is_compact_and_complete():
             assert d["collective_us"] > 0 and d["gathered_wins_equal_sum_of_per_rank_counts"] is True and "expected" in d and 0 < d["step_share_of_region"] < 1
     # what a first multi-GPU line is read against: N x the committed one-rank RCCL rehearsal of the same shape, next to the one-GPU line of that shape
     exp = bench.expected_if_wire_free(8, 20)
-    assert exp and "r05_c_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
+    assert exp and "r05_d_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
     assert 0.9 < exp["weak_scaling_efficiency_if_wire_free"] < 1.0 and exp["collective_us_1rank"] > 0       # step launches / (step launches + collective path), one run
     assert bench.expected_if_wire_free(8, 12345) is None

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Prints the "Numbers" list of DESIGN.md section 6 from the bench lines and counter summaries committed under profiles/ (one source per number).
-usage: python tools/design_numbers.py [name]      (default r05_c)"""
+usage: python tools/design_numbers.py [name]      (default r05_d)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAME = sys.argv[1] if len(sys.argv) > 1 else "r05_c"
+NAME = sys.argv[1] if len(sys.argv) > 1 else "r05_d"
 F = lambda n: json.load(open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (NAME, n))))
 fin, drv, c5, k4, i16, rc, gl = F("final"), F("driver_shape"), F("config5"), F("4096envs"), F("int16"), F("rehearse_rccl_1rank"), F("rehearse_gloo_2ranks_one_gpu")
 pm = json.load(open(os.path.join(ROOT, "profiles", NAME + "_pmc_traffic.json")))["forms"]
