@@ -16,6 +16,19 @@ rows.append("* env-steps/s, persistent rollout form, default 450 timed turns (me
             % (fin["timing"]["repeats"], G(fin), fin["ms_per_step"] * 1e3, fin["timing"]["min_value"] / 1e9, fin["timing"]["max_value"] / 1e9, NAME))
 rows.append("* the driver's shape `--steps 20 --warmup 5` (median of %d regions) — **%.2f G** (%.2f µs/step, kernel %.2f µs/turn; regions %.2f–%.2f G) [`%s_bench_driver_shape.json`]"
             % (drv["timing"]["repeats"], G(drv), drv["ms_per_step"] * 1e3, drv["roofline"]["kernel_ms"] * 1e3, drv["timing"]["min_value"] / 1e9, drv["timing"]["max_value"] / 1e9, NAME))
+# the default command under rocprofv3, with the shader clock of every dispatch
+import re
+dr = open(os.path.join(ROOT, "profiles", NAME + "_default_run_kernel_stats.csv")).read().splitlines()
+m = re.search(r"median (\d+) us = ([\d.]+) us per turn.*roofline.kernel_ms = ([\d.]+)", dr[2])
+clk = [(float(a), float(b)) for a, b in re.findall(r"(\d+)@([\d.]+)", dr[4])]
+slow, fast = max(clk), min(clk)
+rows.append("* the default command under rocprofv3 — median timed region %s µs per turn (the line of that run: %.2f); a 150-turn dispatch lasts %.2f ms at %.2f GHz and %.2f ms at %.2f GHz "
+            "(GRBM_GUI_ACTIVE): %.2f and %.2f M shader cycles — the time follows the clock [`%s_default_run_kernel_stats.csv`]"
+            % (m.group(2), float(m.group(3)) * 1e3, slow[0] / 1e3, slow[1], fast[0] / 1e3, fast[1], slow[0] * slow[1] / 1e3, fast[0] * fast[1] / 1e3, NAME))
+cw = [l for l in open(os.path.join(ROOT, "profiles", NAME + "_clock_warmup_ab.txt")).read().splitlines() if not l.startswith("#")]
+gv = lambda l: float(re.search(r"([\d.]+) G env-steps/s", l).group(1))
+rows.append("* without the clock warm-up (`--clock-warmup-ms 0`, what earlier rounds measured), same box, back to back — driver shape %.2f G against %.2f G, default %.2f G against %.2f G "
+            "[`%s_clock_warmup_ab.txt`]" % (gv(cw[0]), gv(cw[1]), gv(cw[2]), gv(cw[3]), NAME))
 for k, nm, both in (("one_launch_per_turn", "one launch per turn, orders drawn in the kernel", "kernel alone"), ("caller_actions_per_turn", "one launch per turn, orders from a caller tensor (the Gym consumer)", "both kernels of the turn"),
                     ("learner_vs_bot_per_turn", "learner seat vs on-device bot (`evg_step_vs_policy`, stand-in policy)", "both kernels of the turn")):
     g, ms, km, fr = leg(fin, k)
