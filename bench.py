@@ -464,8 +464,7 @@ def main():
             torch.cuda.synchronize(device)
             clock_warmup["turns"] += PHASES
         clock_warmup["ms"] = (time.perf_counter() - t_w) * 1e3
-        scratch.close()
-        del scratch
+        # (the scratch handle is released AFTER the timed regions: freeing 200 MB of device memory takes the host milliseconds during which the GPU would idle)
     if args.warmup > 0:
         rollout(args.warmup, True, args.turns_per_launch, main_fused)
         played += args.warmup
@@ -522,6 +521,9 @@ def main():
             regions[rep][1] = evs[rep][0].elapsed_time(evs[rep][1])      # HIP events on the stream the step kernels run on (torch's current stream)
             if dist_on:
                 regions[rep][2] = evs[rep][1].elapsed_time(evs[rep][2])
+    if args.clock_warmup_ms > 0:
+        scratch.close()
+        del scratch
     if env.check_fault():                           # (never expected: a chunk hand-over fault of a launch plan; raises)
         raise SystemExit("fault")
     played += args.steps * repeats
