@@ -64,7 +64,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 4.0   # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction: what a SIMD sustains with 2 or 4
                                                      # waves on this kernel's instruction mix (tools/micro/inst_rate.hip, profiles/r02_q_*: 4.3-4.8 cycles per
                                                      # instruction per SIMD for mul / f64 / bfe / perm / cndmask / DPP, 2.7 for plain add / xor; the guide's
-                                                     # 2-cycle SIMD-32 issue holds for the simplest ops only).  SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction.
+                                                     # 2-cycle SIMD-32 issue holds for the simplest ops only).  SQ_ACTIVE_INST_VALU = 1 quad-cycle per
+                                                     # instruction.
 NOMINAL_MS_PER_STEP = 0.02   # for the repeat rule of the timed region only (one rule for every rank, box and batch size)
 PHASES = 150                 # episode length of random vs random (server.py:321): the pre-roll spreads phases over it
 
@@ -213,7 +214,8 @@ def expected_if_wire_free(world, steps):
     out = {"value_if_wire_free": world * reh["value"], "per_gpu": reh["value"], "from": "1-rank RCCL rehearsal " + reh_f,
            "collective_us_1rank": dd.get("collective_us"), "step_launches_us_1rank": dd.get("step_launches_us")}
     if dd.get("collective_us") and dd.get("step_launches_us"):
-        # both stream times come from ONE run (two single samples of a 0.4 ms region on different boxes differ by +-8 %): the share of the step launches in launches + collective path
+        # both stream times come from ONE run (two single samples of a 0.4 ms region on different boxes differ by +-8 %): the share of the step launches in
+        # launches + collective path
         out["weak_scaling_efficiency_if_wire_free"] = dd["step_launches_us"] / (dd["step_launches_us"] + dd["collective_us"])
     if one:
         out.update({"one_gpu_value_same_shape": one["value"], "one_gpu_from": one_f})
@@ -246,8 +248,10 @@ def compact_line(full):
     def roof(r):
         if not r:
             return None
-        keep = ("bound", "bound_contract", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "bytes_per_env_step", "bytes_source", "launch_form", "launches_timed",
-                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "hbm_proper_source", "algorithmic_bytes_per_env_step", "traffic_over_algorithmic", "note")
+        keep = ("bound", "bound_contract", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "bytes_per_env_step", "bytes_source", "launch_form",
+                "launches_timed",
+                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "hbm_proper_source", "algorithmic_bytes_per_env_step",
+                "traffic_over_algorithmic", "note")
         o = {k: _r(r[k], 5) for k in keep if k in r and r[k] is not None}
         if "traffic" not in o:
             o["traffic"] = None
@@ -259,7 +263,8 @@ def compact_line(full):
             o["note"] = "working set cache-resident: latency/issue-bound, frac meaningless"
         bm = r.get("beyond_mall")
         if bm:      # (the full object has every pass with its source; the line keeps the fractions)
-            o["beyond_mall_fracs"] = {("cycled_%dMB" % v["working_set_MB"]) if "working_set_MB" in v else k[:24]: _r(v["frac_of_8TBps"]) for k, v in bm.items() if isinstance(v, dict) and "frac_of_8TBps" in v}
+            o["beyond_mall_fracs"] = {("cycled_%dMB" % v["working_set_MB"]) if "working_set_MB" in v else k[:24]: _r(v["frac_of_8TBps"])
+                                      for k, v in bm.items() if isinstance(v, dict) and "frac_of_8TBps" in v}
             w = (bm.get("whole_rounds_one_after_the_other") or {}).get("persistent")
             if w:
                 o["beyond_mall_fracs"]["whole_rounds_262144_envs"] = _r(w["frac_of_8TBps"])
@@ -273,28 +278,34 @@ def compact_line(full):
             if l.get(sub):
                 o[sub] = {k: _r(l[sub][k], 4) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms")}
         if l.get("roofline"):
-            o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}      # (bound, peak, unit and byte source: as in the main roofline object)
+            # (bound, peak, unit and byte source: as in the main roofline object)
+            o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}
         return o
 
     c = full["config"]
-    out = {k: _r(full[k], 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out = {k: _r(full[k], 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                       "dtype", "data")}
     obs_name = c["workload"].rsplit("obs ", 1)[-1].split(" ")[0]
     out["config"] = {"workload": "%d concurrent DemoMap games per GPU, %s, persistent rollout form, auto-reset, obs %s [N,2,105]" % (
                          c["envs_per_gpu"], "random_actions vs random_actions drawn on device" if "random_actions" in c["workload"] else
                          "on-device Cycle_BRush_Turn25 vs SwarmAgent fused into the step kernel (BASELINE config 5)", obs_name),
                      "window": "desynchronised steady state: 150-turn pre-roll (phases hash(e) mod 150) + 150 settle turns",
-                     **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash", "episodes_finished_rank0",
+                     **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash",
+                                          "episodes_finished_rank0",
                                           "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
                      "one_launch_per_turn": leg(c.get("one_launch_per_turn")), "caller_actions_per_turn": leg(c.get("caller_actions_per_turn")),
-                     "learner_vs_bot_per_turn": leg(c.get("learner_vs_bot_per_turn")), "learner_smart_actions_vs_bot_per_turn": leg(c.get("learner_smart_actions_vs_bot_per_turn")),
+                     "learner_vs_bot_per_turn": leg(c.get("learner_vs_bot_per_turn")),
+                     "learner_smart_actions_vs_bot_per_turn": leg(c.get("learner_smart_actions_vs_bot_per_turn")),
                      "pipelined_halves_per_turn": leg(c.get("pipelined_halves_per_turn")),
                      "obs_float64": leg(c.get("obs_float64")),
                      "without_observations": leg(c.get("without_observations"))}
     out["roofline"] = roof(full["roofline"])
     if "timing" in full:
         t = full["timing"]
-        out["timing"] = {"repeats": t["repeats"], "reported": t["reported"], "min_ms_per_step": _r(t["min_ms_per_step"], 5), "max_ms_per_step": _r(t["max_ms_per_step"], 5),
-                         "min_value": _r(t["min_value"], 5), "max_value": _r(t["max_value"], 5), "clock_warmup_ms": _r(t.get("clock_warmup", {}).get("ms", 0.0), 3)}
+        out["timing"] = {"repeats": t["repeats"], "reported": t["reported"], "min_ms_per_step": _r(t["min_ms_per_step"], 5),
+                         "max_ms_per_step": _r(t["max_ms_per_step"], 5),
+                         "min_value": _r(t["min_value"], 5), "max_value": _r(t["max_value"], 5),
+                         "clock_warmup_ms": _r(t.get("clock_warmup", {}).get("ms", 0.0), 3)}
     if "roofline_valu_issue" in full:
         v = full["roofline_valu_issue"]
         out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "frac", "valu_insts_per_wave_turn", "source")}
@@ -306,14 +317,16 @@ def compact_line(full):
         pr = d.get("per_rank") or []          # per rank, as columns (rank = position): an 8-rank line must still fit a driver's tail
         d["per_rank"] = {k: [_r(r[k], 4) for r in pr] for k in ("seconds", "kernel_ms_per_step", "collective_us")}
         if d.get("expected"):
-            d["expected"] = {k: _r(v, 5) for k, v in d["expected"].items() if k in ("value_if_wire_free", "per_gpu", "weak_scaling_efficiency_if_wire_free", "collective_us_1rank")}
+            d["expected"] = {k: _r(v, 5) for k, v in d["expected"].items() if k in ("value_if_wire_free", "per_gpu", "weak_scaling_efficiency_if_wire_free",
+                                                                                    "collective_us_1rank")}
         for k in ("collective_us", "step_launches_us", "step_share_of_region"):
             d[k] = _r(d.get(k), 5)
         out["distributed"] = d
     if "cpu_baseline" in full:
         b = full["cpu_baseline"]
         out["cpu_baseline"] = {"value": _r(b["value"], 5), "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "obs_dtype": b.get("obs_dtype"),
-                               "sample": b["sample"].split(" (random vs random")[0] + ", random vs random incl. action generation + f64 obs; C port of the reference's turn loop, OpenMP"}
+                               "sample": b["sample"].split(" (random vs random")[0]
+                               + ", random vs random incl. action generation + f64 obs; C port of the reference's turn loop, OpenMP"}
         if "same_games_as_gpu" in b:
             g = b["same_games_as_gpu"]
             out["cpu_baseline"]["same_games_as_gpu"] = {k: g[k] for k in ("envs", "turns", "equal", "cpu_wins_p0_p1_tie", "gpu_wins_p0_p1_tie")}
@@ -336,20 +349,38 @@ def main():
     ap.add_argument("--workload", default="random", choices=["random", "scripted"],
                     help="random: BASELINE metric config (random vs random); scripted: BASELINE config 5 (cycle_rush_turn25 vs swarm)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
-    ap.add_argument("--rehearse-distributed", action="store_true", help="diagnostics only: run the N > 1 code path (process group, pack + gather, per-rank times) with a ONE-rank group on one GPU")
-    ap.add_argument("--caller-actions", action="store_true", help="profiling runs: the MAIN leg runs the caller-supplied-actions path (per turn evg_random_actions into a tensor + evg_step); needs --turns-per-launch 1")
-    ap.add_argument("--learner-seat", action="store_true", help="profiling runs: the MAIN leg runs the learner-seat path (per turn evg_random_actions_seat into a tensor + evg_step_vs_policy); needs --turns-per-launch 1")
-    ap.add_argument("--opponent", default="random", help="the on-device bot of the learner-seat leg (a name from everglades_amd._lib.POLICY_NAMES); random = the headline's game mix")
-    ap.add_argument("--timing", default="torch", choices=["native", "torch"], help="single-rank timed region: launch duration from two pre-created torch events around an untimed call, one synchronisation in the closing bracket (default; 1.05-1.1 us per step of host time in the 20-step shape, "
-                         "tools/driver_shape_timing_ab.sh) or from the native driver's own events, read inside the call, which synchronises itself (1.2-4.7 us)")
-    ap.add_argument("--collective", default="torch", choices=["torch", "evg"], help="N > 1: the gather of episode results through torch.distributed (default; backend nccl = RCCL) or through the "
-                         "library's own RCCL entry points (evg_comm_init / evg_gather_returns: pack kernel + grouped send / receive on the launches' stream, no framework stream hop)")
-    ap.add_argument("--repeats", type=int, default=0, help="how often the exact K-step region is timed (value = the median region); 0 = auto: 9 when K x a nominal 0.02 ms < 50 ms (K <= 2500), else 1")
-    ap.add_argument("--clock-warmup-ms", type=float, default=80.0, help="untimed: a SCRATCH handle of the same size plays rollouts for this long right before the --warmup steps, so that the "
-                    "timed regions run at the shader clock a long rollout sustains (the governor needs 30-40 ms of load to get there: profiles/r05_d_default_run_kernel_stats.csv); 0 = off")
-    ap.add_argument("--cache-mib", type=int, default=0, help="profiling runs: evg_config.cache_mib of the handle (the memory-side cache budget a chunked rollout launch may cycle through; 0 = the device's)")
+    ap.add_argument("--rehearse-distributed", action="store_true",
+                    help="diagnostics only: run the N > 1 code path (process group, pack + gather, per-rank times) with a ONE-rank group on one GPU")
+    ap.add_argument("--caller-actions", action="store_true",
+                    help="profiling runs: the MAIN leg runs the caller-supplied-actions path (per turn evg_random_actions into a tensor + evg_step); needs "
+                         "--turns-per-launch 1")
+    ap.add_argument("--learner-seat", action="store_true",
+                    help="profiling runs: the MAIN leg runs the learner-seat path (per turn evg_random_actions_seat into a tensor + evg_step_vs_policy); "
+                         "needs --turns-per-launch 1")
+    ap.add_argument("--opponent", default="random",
+                    help="the on-device bot of the learner-seat leg (a name from everglades_amd._lib.POLICY_NAMES); random = the headline's game mix")
+    ap.add_argument("--timing", default="torch", choices=["native", "torch"],
+                    help="single-rank timed region: launch duration from two pre-created torch events around an untimed call, one synchronisation in the "
+                         "closing bracket (default; 1.05-1.1 us per step of host time in the 20-step shape, "
+                         "tools/driver_shape_timing_ab.sh) or from the native driver's own events, read inside the call, which synchronises itself (1.2-4.7 "
+                         "us)")
+    ap.add_argument("--collective", default="torch", choices=["torch", "evg"],
+                    help="N > 1: the gather of episode results through torch.distributed (default; backend nccl = RCCL) or through the "
+                         "library's own RCCL entry points (evg_comm_init / evg_gather_returns: pack kernel + grouped send / receive on the launches' stream, "
+                         "no framework stream hop)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how often the exact K-step region is timed (value = the median region); 0 = auto: 9 when K x a nominal 0.02 ms < 50 ms (K <= "
+                         "2500), else 1")
+    ap.add_argument("--clock-warmup-ms", type=float, default=80.0,
+                    help="untimed: a SCRATCH handle of the same size plays rollouts for this long right before the --warmup steps, so that the "
+                    "timed regions run at the shader clock a long rollout sustains (the governor needs 30-40 ms of load to get there: "
+                    "profiles/r05_d_default_run_kernel_stats.csv); 0 = off")
+    ap.add_argument("--cache-mib", type=int, default=0,
+                    help="profiling runs: evg_config.cache_mib of the handle (the memory-side cache budget a chunked rollout launch may cycle through; 0 = "
+                         "the device's)")
     ap.add_argument("--pipeline", type=int, default=2, help="parts of the double-buffered leg (everglades_amd.PipelinedVecEnv)")
-    ap.add_argument("--details", default="", help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
+    ap.add_argument("--details", default="",
+                    help="also write the FULL result object (every note and source string; the stdout line is its compact form) to this file")
     ap.add_argument("--library", default=None, help="diagnostics only (tools/ab.sh): path of another build of libevg.so")
     ap.add_argument("--diag-lanes", type=int, default=0, help="diagnostics only: kernel variant of libevg_diag.so (evg_diag_configure lanes)")
     args = ap.parse_args()
@@ -413,7 +444,8 @@ def main():
             per turn the action kernel(s) write the orders into a tensor and evg_step reads them -- the caller-supplied-actions path.
             Returns the summed stream time in ms (HIP events recorded on that stream: around every persistent launch, or around the
             whole loop of single-turn launches)."""
-            if fused == "learner":                           # per turn: evg_random_actions_seat -> tensor [N,7,2] -> evg_step_vs_policy (bot inside the step kernel)
+            # per turn: evg_random_actions_seat -> tensor [N,7,2] -> evg_step_vs_policy (bot inside the step kernel)
+            if fused == "learner":
                 out = env.rollout_vs(nsteps, args.opponent, seat=0, time_kernel=timed)
                 return out[-1] * nsteps if timed else 0.0
             kw = dict(time_kernel=timed, fused=fused, turns_per_launch=tpl, observe=observe, record_actions=observe, prepare=prepare)
@@ -422,10 +454,12 @@ def main():
             return out[-1] * nsteps if timed else 0.0
 
         desynchronise(env, first, args.workload, rollout)
-        settle = rollout(PHASES, True, args.turns_per_launch, main_fused)   # settle: one more episode length in the launch form that is timed (also creates its timing events)
+        # settle: one more episode length in the launch form that is timed (also creates its timing events)
+        settle = rollout(PHASES, True, args.turns_per_launch, main_fused)
         return env, rollout, settle
 
-    main_fused = "learner" if args.learner_seat else (not args.caller_actions)   # --caller-actions / --learner-seat (profiling runs): the main leg itself pays two launches per turn
+    # --caller-actions / --learner-seat (profiling runs): the main leg itself pays two launches per turn
+    main_fused = "learner" if args.learner_seat else (not args.caller_actions)
     if (args.caller_actions or args.learner_seat) and args.turns_per_launch != 1:
         raise SystemExit("--caller-actions / --learner-seat need --turns-per-launch 1 (orders from a tensor exist in the single-turn form only)")
     env, rollout, settle_ms = make_env(args.obs_dtype)
@@ -446,7 +480,8 @@ def main():
     if dist_on:      # first use opens the RCCL channels of the gather: not part of the timed region
         run_collective()
     if main_fused is True:
-        rollout(args.steps, False, args.turns_per_launch, True, prepare=True)     # capture + instantiate the graphs of the K-step launch shape now (nothing is played)
+        # capture + instantiate the graphs of the K-step launch shape now (nothing is played)
+        rollout(args.steps, False, args.turns_per_launch, True, prepare=True)
 
     # ---- clock warm-up (untimed, not part of the measured games).  The shader clock of an MI355X that has just started working climbs from ~1.9-2.1 GHz to the
     # ~2.35 GHz it then sustains over the first 30-40 ms of load, and this kernel's time is a constant number of CYCLES (33 k per turn at 65 536 envs: the
@@ -455,7 +490,8 @@ def main():
     # plays 150-turn rollouts for --clock-warmup-ms right before the W warm-up steps; the measured handle, its games and the W / K contract are untouched.
     clock_warmup = {"requested_ms": args.clock_warmup_ms, "ms": 0.0, "turns": 0}
     if args.clock_warmup_ms > 0:
-        scratch = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed + 1, env_id_base=first, obs_dtype=args.obs_dtype, auto_reset=True, library=args.library)
+        scratch = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed + 1, env_id_base=first, obs_dtype=args.obs_dtype, auto_reset=True,
+                                       library=args.library)
         scratch.reset()
         torch.cuda.synchronize(device)
         t_w = time.perf_counter()
@@ -494,9 +530,9 @@ def main():
             k_ms = rollout(args.steps, True, args.turns_per_launch, main_fused)
             barrier()
         elif not dist_on:
-            # the launches are only ENQUEUED (no event read-out, no synchronisation inside the call); their duration is taken from two stream events (created and
-            # recorded once before the region: torch creates an event at its first record()) after the closing bracket, whose torch.cuda.synchronize() is then
-            # the one host wait of the timed region
+            # the launches are only ENQUEUED (no event read-out, no synchronisation inside the call); their duration is taken from two stream events (created
+            # and recorded once before the region: torch creates an event at its first record()) after the closing bracket, whose torch.cuda.synchronize() is
+            # then the one host wait of the timed region
             evs[rep][0].record()
             rollout(args.steps, False, args.turns_per_launch, main_fused)
             evs[rep][1].record()
@@ -542,13 +578,19 @@ def main():
     kernel_ms_sum = regions[med][1]
     collective_ms = regions[med][2]
     if dist_on:
-        per_rank = [{"rank": r, "seconds": float(allr[r, med, 0]), "env_steps_per_s": n_local * args.steps / float(allr[r, med, 0]), "kernel_ms_per_step": float(allr[r, med, 1]),
+        per_rank = [{"rank": r, "seconds": float(allr[r, med, 0]), "env_steps_per_s": n_local * args.steps / float(allr[r, med, 0]),
+                     "kernel_ms_per_step": float(allr[r, med, 1]),
                      "collective_us": float(allr[r, med, 2])} for r in range(world)]
     timing = {"repeats": repeats, "reported": "median region", "region_ms": [x * 1e3 for x in region_s], "min_ms_per_step": min(region_s) / args.steps * 1e3,
-              "max_ms_per_step": max(region_s) / args.steps * 1e3, "min_value": total * args.steps / max(region_s), "max_value": total * args.steps / min(region_s),
-              "rule": "R = 9 when K x 0.02 ms (nominal) < 50 ms, else 1 (--repeats N forces N); every region = exactly K steps between barrier + synchronize brackets",
-              "clock_warmup": dict(clock_warmup, note="untimed rollouts of a SCRATCH handle right before the W warm-up steps: the timed regions run at the shader clock a long "
-                                                      "rollout sustains instead of inside the governor's ramp of the first 30-40 ms (--clock-warmup-ms 0 = off)")}
+              "max_ms_per_step": max(region_s) / args.steps * 1e3, "min_value": total * args.steps / max(region_s),
+              "max_value": total * args.steps / min(region_s),
+              "rule": "R = 9 when K x 0.02 ms (nominal) < 50 ms, else 1 (--repeats N forces N); every region = exactly K steps between barrier + synchronize "
+                      "brackets",
+              "clock_warmup": dict(clock_warmup,
+                                   note="untimed rollouts of a SCRATCH handle right before the W warm-up steps: the timed regions run at the shader clock a "
+                                        "long "
+                                                      "rollout sustains instead of inside the governor's ramp of the first 30-40 ms (--clock-warmup-ms 0 = "
+                                                      "off)")}
     step_kernel_ms = kernel_ms_sum / args.steps
     st = env.episode_stats()
     if not dist_on:
@@ -586,12 +628,14 @@ def main():
             per_turn_launch = per_turn_leg(True)
         if main_fused != "learner":
             learner_leg = per_turn_leg("learner")
-            learner_leg["path"] = ("per turn: evg_random_actions_seat -> caller tensor [N,7,2] (seat 0) -> evg_step_vs_policy(opponent = on-device `%s` on seat 1, evaluated inside the step "
+            learner_leg["path"] = ("per turn: evg_random_actions_seat -> caller tensor [N,7,2] (seat 0) -> evg_step_vs_policy(opponent = on-device `%s` on "
+                                   "seat 1, evaluated inside the step "
                                    "kernel; only seat 0's observation [N,105] written) -- evaluate.py:85-93,143-152 with a learner on one seat" % args.opponent)
         if main_fused is True and args.workload == "random":
-            # The learner-seat turn with the Smart_State family's own decode on the device: per turn evg_smart_actions(Q [N,12,5] -> 7 order rows: DQNAgent.get_best_actions) +
-            # evg_step_vs_policy; Q = one of 8 prepared random tensors (the stand-in for the consumer's network output: QNetwork 59-60-60-5 in the reference, not ours).
-            # A second figure adds evg_smart_state_compact (the network's input) in front: observation -> features -> [network] -> orders -> step, no host or framework glue.
+            # The learner-seat turn with the Smart_State family's own decode on the device: per turn evg_smart_actions(Q [N,12,5] -> 7 order rows:
+            # DQNAgent.get_best_actions) + evg_step_vs_policy; Q = one of 8 prepared random tensors (the stand-in for the consumer's network output: QNetwork
+            # 59-60-60-5 in the reference, not ours). A second figure adds evg_smart_state_compact (the network's input) in front: observation -> features ->
+            # [network] -> orders -> step, no host or framework glue.
             qs = [torch.randn((n_local, 12, 5), device=device) for _ in range(8)]
             sobs = env.observe_seat(0)
             sh = torch.empty((n_local, 34), dtype=torch.float32, device=device)
@@ -614,14 +658,18 @@ def main():
                 e1.record()
                 barrier()
                 d1 = time.perf_counter() - t1
-                return {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": e0.elapsed_time(e1) / 150, "launches_per_turn": 3 if features else 2}
+                return {"env_steps_per_s": total * 150 / d1, "ms_per_step": d1 / 150 * 1e3, "kernel_ms": e0.elapsed_time(e1) / 150,
+                        "launches_per_turn": 3 if features else 2}
             smart_leg_ = smart_leg(False)
             smart_leg_["with_features"] = smart_leg(True)
-            smart_leg_["path"] = ("per turn, from a Python loop over the C-ABI: evg_smart_actions(Q [N,12,5] f32, one-seat obs) -> [N,7,2] orders (DQNAgent.get_best_actions on the device) -> "
-                                  "evg_step_vs_policy(opponent `%s` inside the step kernel); with_features: evg_smart_state_compact in front (the network's input)" % args.opponent)
+            smart_leg_["path"] = ("per turn, from a Python loop over the C-ABI: evg_smart_actions(Q [N,12,5] f32, one-seat obs) -> [N,7,2] orders "
+                                  "(DQNAgent.get_best_actions on the device) -> "
+                                  "evg_step_vs_policy(opponent `%s` inside the step kernel); with_features: evg_smart_state_compact in front (the network's "
+                                  "input)" % args.opponent)
         if main_fused is True:
             caller_leg = per_turn_leg(False)
-            caller_leg["path"] = ("per turn: evg_random_actions -> caller tensor [N,2,7,2] -> evg_step(actions) (evaluate.py:143-152 with on-device agents)" if args.workload == "random" else
+            caller_leg["path"] = ("per turn: evg_random_actions -> caller tensor [N,2,7,2] -> evg_step(actions) (evaluate.py:143-152 with on-device agents)"
+                                  if args.workload == "random" else
                                   "per turn: evg_scripted_actions x 2 (reading the previous observations) -> caller tensor -> evg_step(actions)")
         if args.turns_per_launch > 1 and main_fused is True:
             # the persistent form without observations and without recording the orders (evg_rollout_*(obs_out = NULL, actions_buf = NULL)):
@@ -633,11 +681,13 @@ def main():
             barrier()
             dq = time.perf_counter() - t1
             no_obs_leg = {"env_steps_per_s": total * 150 / dq, "ms_per_step": dq / 150 * 1e3, "kernel_ms": kq / 150, "turns_per_launch": args.turns_per_launch,
-                          "what": "persistent rollout, no observation image / write-out, orders not recorded: rewards, done flags, scores and episode results only"}
+                          "what": "persistent rollout, no observation image / write-out, orders not recorded: rewards, done flags, scores and episode "
+                                  "results only"}
         if main_fused is True and args.workload == "random" and n_local >= 64:
             # the double-buffered consumer (everglades_amd.PipelinedVecEnv): two half-batch handles on two streams, global env ids preserved, each playing
             # one launch per turn FREE-RUNNING -- what the overlapped pattern (policy on half A while half B steps) converges to with a cheap policy
-            pipe = evg.PipelinedVecEnv(n_local, pipeline=args.pipeline, device=device, seed=args.seed, env_id_base=first, obs_dtype=args.obs_dtype, auto_reset=True)
+            pipe = evg.PipelinedVecEnv(n_local, pipeline=args.pipeline, device=device, seed=args.seed, env_id_base=first, obs_dtype=args.obs_dtype,
+                                       auto_reset=True)
             pipe.reset()
             phase = episode_phase(torch.arange(first, first + n_local, device=device, dtype=torch.int64))
             for j in range(PHASES):
@@ -649,19 +699,25 @@ def main():
             kp = pipe.rollout_random_free(600, time_kernel=True)      # (600 turns: the start of one host thread per part is inside the wall clock)
             barrier()
             dp = time.perf_counter() - t1
-            pipe_leg = {"env_steps_per_s": total * 600 / dp, "ms_per_step": dp / 600 * 1e3, "kernel_ms": max(kp), "turns_timed": 600, "parts": args.pipeline, "envs_per_part": [c for _, c in pipe.ranges],
-                        "kernel_ms_is": "stream time per turn of the slowest part (two HIP events around its 600 single-turn launches); ms_per_step is the wall clock per turn of the WHOLE batch",
+            pipe_leg = {"env_steps_per_s": total * 600 / dp, "ms_per_step": dp / 600 * 1e3, "kernel_ms": max(kp), "turns_timed": 600, "parts": args.pipeline,
+                        "envs_per_part": [c for _, c in pipe.ranges],
+                        "kernel_ms_is": "stream time per turn of the slowest part (two HIP events around its 600 single-turn launches); ms_per_step is the "
+                                        "wall clock per turn of the WHOLE batch",
                         "stream_ms_per_turn_of_every_part": kp, "launches_per_turn": args.pipeline,
-                        "what": "PipelinedVecEnv.rollout_random_free: every part plays one launch per turn (orders drawn in the step kernel) on its own stream, nothing joins them"}
-            # ... and the learner-seat turn on the same two parts: per part and turn the learner's stand-in kernel + evg_step_vs_policy (bot inside), free-running
+                        "what": "PipelinedVecEnv.rollout_random_free: every part plays one launch per turn (orders drawn in the step kernel) on its own "
+                                "stream, nothing joins them"}
+            # ... and the learner-seat turn on the same two parts: per part and turn the learner's stand-in kernel + evg_step_vs_policy (bot inside),
+            # free-running
             pipe.rollout_vs_free(16, args.opponent, seat=0, time_kernel=True)
             barrier()
             t1 = time.perf_counter()
             kl = pipe.rollout_vs_free(600, args.opponent, seat=0, time_kernel=True)
             barrier()
             dl = time.perf_counter() - t1
-            pipe_leg["learner_vs_bot"] = {"env_steps_per_s": total * 600 / dl, "ms_per_step": dl / 600 * 1e3, "kernel_ms": max(kl), "launches_per_turn": 2 * args.pipeline,
-                                          "what": "PipelinedVecEnv.rollout_vs_free: per part and turn evg_random_actions_seat + evg_step_vs_policy(opponent `%s` inside the step kernel)" % args.opponent}
+            pipe_leg["learner_vs_bot"] = {"env_steps_per_s": total * 600 / dl, "ms_per_step": dl / 600 * 1e3, "kernel_ms": max(kl),
+                                          "launches_per_turn": 2 * args.pipeline,
+                                          "what": "PipelinedVecEnv.rollout_vs_free: per part and turn evg_random_actions_seat + evg_step_vs_policy(opponent "
+                                                  "`%s` inside the step kernel)" % args.opponent}
             pipe.close()
         if args.obs_dtype != "float64":
             env64, rollout64, _ = make_env("float64")
@@ -696,13 +752,15 @@ def main():
                 # start, written at its end) is re-scaled to the turns per launch that were timed here
                 bpe = form["bytes_per_env_step_steady"] + form["state_round_trip_bytes_per_env"] / turns_per_launch_timed
                 achieved = bpe * n_local / (kernel_ms * 1e-3) / 1e9
-                r.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": bpe * n_local * turns_per_launch_timed, "traffic_unit": "bytes per launch",
+                r.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": bpe * n_local * turns_per_launch_timed,
+                          "traffic_unit": "bytes per launch",
                           "bytes_per_env_step": bpe, "bytes_source": pmc["_file"] + " [%s]" % form_key,
                           "kernel_us_rocprof": form.get("kernel_us_per_turn"), "frac_at_rocprof_kernel_time": form.get("frac_of_8TBps"),
                           "ratio_to_mandatory_outputs": bpe / mand})
-                # this DESIGN's algorithmic bytes: the outputs a turn must write + every health row combat hit, read once and written once --
-                # the rows written are what WRITE_SIZE shows beyond the outputs (persistent form; single-turn forms also move the state words: in `mand`-free terms
-                # their figure is an upper bound).  traffic / algorithmic > 1 is over-fetch: whole 128-byte lines for 64-byte rows, straddling rows
+                # this DESIGN's algorithmic bytes: the outputs a turn must write + every health row combat hit, read once and written
+                # once -- the rows written are what WRITE_SIZE shows beyond the outputs (persistent form; single-turn forms also move the state words: in
+                # `mand`-free terms their figure is an upper bound).  traffic / algorithmic > 1 is over-fetch: whole 128-byte lines for 64-byte rows,
+                # straddling rows
                 if form.get("WRITE_SIZE_KB_mean") and form_key == "persistent":
                     rows_written = max(0.0, form["WRITE_SIZE_KB_mean"] * 1024.0 / form["turns_per_launch"] / n_local - mand)
                     r["algorithmic_bytes_per_env_step"] = mand + 2.0 * rows_written
@@ -710,44 +768,57 @@ def main():
             else:
                 achieved = mand * n_local / (kernel_ms * 1e-3) / 1e9
                 r.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_env_step": mand,
-                          "bytes_source": "mandatory outputs only: a lower bound (profiles/ holds no PMC pass of this build, hash %s, for %s at %d envs, workload %s, %s observations)"
+                          "bytes_source": "mandatory outputs only: a lower bound (profiles/ holds no PMC pass of this build, hash %s, for %s at %d envs, "
+                                          "workload %s, %s observations)"
                                           % (kernel_source_hash(), form_key, n_local, args.workload, args.obs_dtype)})
             return r
 
-        main_form = "persistent" if tpl > 1 else ("caller_actions_per_turn" if args.caller_actions else ("learner_vs_bot_per_turn" if args.learner_seat else "one_launch_per_turn"))
+        main_form = "persistent" if tpl > 1 else ("caller_actions_per_turn" if args.caller_actions
+                                                  else ("learner_vs_bot_per_turn" if args.learner_seat else "one_launch_per_turn"))
         roof = hbm_roofline(main_form, step_kernel_ms, args.steps / launches)
         n_launch, plan_text = env.launch_plan(tpl)
         roof.update({"kernel": plan_text, "kernel_launches_per_rollout_launch": n_launch, "launch_form": main_form,
-                     "kernel_ms_is": ("HIP-event duration of every timed launch (two events on the stream it is launched on), summed / K" if tpl > 1 else "stream time per turn (two HIP events around the timed launches)") if not dist_on else
+                     "kernel_ms_is": ("HIP-event duration of every timed launch (two events on the stream it is launched on), summed / K" if tpl > 1
+                                      else "stream time per turn (two HIP events around the timed launches)") if not dist_on else
                                      "stream time per turn: two HIP events on the launches' stream around all timed launches / K",
-                     "launches_timed": launches, "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch, "launch_ms": launch_ms,
-                     "bytes_source_is": "rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction, calibrated in the same passes), per env-step, "
+                     "launches_timed": launches, "turns_per_launch_timed": args.steps / launches, "env_steps_per_launch": env_steps_per_launch,
+                     "launch_ms": launch_ms,
+                     "bytes_source_is": "rocprofv3 PMC passes of this build (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction, calibrated in the same passes), "
+                                        "per env-step, "
                                         "times the env-steps of the timed launches",
                      "survey_8d_bytes_per_env_step": SURVEY_ALGO_BYTES_PER_ENV_STEP,
                      "survey_8d_rate_GBps": SURVEY_ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9,
                      "survey_8d_frac": SURVEY_ALGO_BYTES_PER_ENV_STEP * n_local / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "survey_8d_note": "SURVEY 8(d)'s byte model (the whole 1 780-byte state read + written every turn: 4 530 B per env-step) priced at this kernel time: ABOVE 1, "
-                                       "i.e. the model is not applicable to this design -- the persistent form keeps group / node / stamp words on chip for the launch and "
-                                       "touches only the float64 health rows combat hits; the game work itself is checked against the oracle (cpu_baseline.same_games_as_gpu). "
+                     "survey_8d_note": "SURVEY 8(d)'s byte model (the whole 1 780-byte state read + written every turn: 4 530 B per env-step) priced at this "
+                                       "kernel time: ABOVE 1, "
+                                       "i.e. the model is not applicable to this design -- the persistent form keeps group / node / stamp words on chip for "
+                                       "the launch and "
+                                       "touches only the float64 health rows combat hits; the game work itself is checked against the oracle "
+                                       "(cpu_baseline.same_games_as_gpu). "
                                        "Never the roofline numerator"})
         if roof.get("bytes_per_env_step"):
             roof["ratio_survey_8d_to_measured"] = SURVEY_ALGO_BYTES_PER_ENV_STEP / roof["bytes_per_env_step"]
         if pmc and roof["bytes_per_env_step"] < 0.5 * mand:
-            roof["note"] = ("the counters see fewer bytes than the kernel writes: the working set of this batch (%.0f MB) stays in L2 / Infinity Cache, the launch is "
+            roof["note"] = ("the counters see fewer bytes than the kernel writes: the working set of this batch (%.0f MB) stays in L2 / Infinity Cache, the "
+                            "launch is "
                             "latency- and issue-bound and `frac` says nothing about it" % (n_local * (1773 + 4 * 210 + 112) / 1e6))
-        # What the bytes are.  FETCH_SIZE / WRITE_SIZE count requests between the L2s and the fabric, Infinity-Cache (256 MiB) hits included (MI355X_MICROARCH.md, "HBM"),
-        # and a persistent launch works through its batch in rounds of resident workgroups (65 536 envs on a whole MI355X) whose working set fits that cache:
-        # the bound this object prices is then the FABRIC (L2 <-> Infinity Cache / HBM), not DRAM, and `bound` says so.
+        # What the bytes are.  FETCH_SIZE / WRITE_SIZE count requests between the L2s and the fabric, Infinity-Cache (256 MiB) hits included
+        # (MI355X_MICROARCH.md, "HBM"), and a persistent launch works through its batch in rounds of resident workgroups (65 536 envs on a whole MI355X) whose
+        # working set fits that cache: the bound this object prices is then the FABRIC (L2 <-> Infinity Cache / HBM), not DRAM, and `bound` says so.
         obs_b = {"float32": 4, "float64": 8, "int16": 2}[args.obs_dtype] * 210
         round_ws = min(n_local, 65536) * (1773 + obs_b + 112 + 32)
         if pmc and round_ws <= (256 << 20):
             roof["bound"] = "fabric"
             roof["bound_contract"] = "hbm"
-            roof["bound_is"] = ("fabric: requests between the L2s and the Infinity Cache / HBM.  The working set of a round of resident workgroups (%.0f MB) is inside the 256 MiB "
-                                "Infinity Cache, so these bytes are NOT all DRAM traffic; the counters cannot separate cache hits.  `peak` is the HBM3E figure the contract asks "
+            roof["bound_is"] = ("fabric: requests between the L2s and the Infinity Cache / HBM.  The working set of a round of resident workgroups (%.0f MB) "
+                                "is inside the 256 MiB "
+                                "Infinity Cache, so these bytes are NOT all DRAM traffic; the counters cannot separate cache hits.  `peak` is the HBM3E "
+                                "figure the contract asks "
                                 "for (8 TB/s); `hbm_proper_frac` is the same kernel made to leave the cache" % (round_ws / 1e6))
-        # ... and the same kernel when its launch does leave the cache.  ONE number (`hbm_proper_frac`), one source: the pass with the LARGEST cycled working set.
-        #   cycled          the diagnostic library's chunked form forced over 262 144 envs: every env of a 723 MB working set (2.7 x the cache) is revisited once
+        # ... and the same kernel when its launch does leave the cache.  ONE number (`hbm_proper_frac`), one source: the pass with the LARGEST cycled working
+        # set.
+        # cycled          the diagnostic library's chunked form forced over 262 144 envs: every env of a 723 MB working set (2.7 x the cache) is revisited
+        #  once
         #                   per 25-turn chunk -- the HBM figure proper
         #   product_cycled  libevg.so itself, a plan it really launches: 131 071 envs with evg_config.cache_mib raised to 1 024, so that the plan is ONE chunked
         #                   launch cycling through 359 MB (1.34 x the cache: still mostly cache-resident, reported next to the other).  With the default budget
@@ -765,7 +836,8 @@ def main():
                         "ns_per_env_step": fb["kernel_us_per_turn"] * 1e3 / d["envs"], "ns_per_env_step_at_65536": fs["kernel_us_per_turn"] * 1e3 / 65536,
                         "traffic_TBps": fb["traffic_TBps"], "frac_of_8TBps": fb["frac_of_8TBps"], "source": d["_file"]}
             if big:
-                bm["whole_rounds_one_after_the_other"] = {k: cmp_form(big, k) for k in ("persistent", "one_launch_per_turn") if k in big["forms"] and k in pmc["forms"]}
+                bm["whole_rounds_one_after_the_other"] = {k: cmp_form(big, k) for k in ("persistent",
+                                                                                        "one_launch_per_turn") if k in big["forms"] and k in pmc["forms"]}
             if cyc and "persistent" in cyc["forms"]:
                 bm["diag_library_chunked_over_262144_envs"] = cmp_form(cyc, "persistent")
             if prod and "persistent" in prod["forms"]:
@@ -774,9 +846,12 @@ def main():
             if hp:
                 roof["hbm_proper_frac"] = hp["frac_of_8TBps"]
                 roof["hbm_proper_source"] = hp["source"]
-                roof["hbm_proper_is"] = ("the persistent kernel in a launch that cycles through a working set the Infinity Cache cannot hold (%d envs, %d MB, every env revisited once per "
-                                         "25-turn chunk): the same instruction stream and the same bytes per env-step (%.0f) at %.3f instead of %.3f ns per env-step = %.2f TB/s = %.2f of "
-                                         "the HBM peak" % (hp["envs"], hp["working_set_MB"], hp["bytes_per_env_step"], hp["ns_per_env_step"], hp["ns_per_env_step_at_65536"],
+                roof["hbm_proper_is"] = ("the persistent kernel in a launch that cycles through a working set the Infinity Cache cannot hold (%d envs, %d "
+                                         "MB, every env revisited once per "
+                                         "25-turn chunk): the same instruction stream and the same bytes per env-step (%.0f) at %.3f instead of %.3f ns per "
+                                         "env-step = %.2f TB/s = %.2f of "
+                                         "the HBM peak" % (hp["envs"], hp["working_set_MB"], hp["bytes_per_env_step"], hp["ns_per_env_step"],
+                                                           hp["ns_per_env_step_at_65536"],
                                                            hp["traffic_TBps"], hp["frac_of_8TBps"]))
             roof["beyond_mall"] = bm
         for leg, key in ((per_turn_launch, "one_launch_per_turn"), (caller_leg, "caller_actions_per_turn"), (learner_leg, "learner_vs_bot_per_turn")):
@@ -788,7 +863,8 @@ def main():
             k = sq["kernels"]["persistent" if tpl > 1 else "one_launch_per_turn"]
             insts = k["valu_insts_per_wave_turn"] * ((n_local + 31) // 32)
             ach = insts / (step_kernel_ms * 1e-3)
-            valu = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s", "frac": ach / VALU_PEAK_WAVE_INSTS_PER_S,
+            valu = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s",
+                    "frac": ach / VALU_PEAK_WAVE_INSTS_PER_S,
                     "valu_insts_per_wave_turn": k["valu_insts_per_wave_turn"], "wave_cycles_per_wave_turn": k.get("wave_cycles_per_wave_turn"),
                     "source": sq["_file"], "peak_is": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
         out = {
@@ -797,14 +873,20 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": ("%d concurrent DemoMap games per GPU, random_actions vs random_actions drawn on device (fused into the "
-                                    "step kernel, orders written to an [N,2,7,2] tensor; persistent rollout form, see turns_per_launch), auto-reset, obs %s [N,2,105]" if args.workload == "random" else
-                                    "%d concurrent DemoMap games per GPU, on-device Cycle_BRush_Turn25 vs SwarmAgent (BASELINE config 5; both bots fused into the "
-                                    "step kernel, orders written out; episodes end by BaseCapture after 84-94 turns), auto-reset, obs %s [N,2,105]") % (n_local, args.obs_dtype),
-                       "window": "desynchronised steady state: 150-turn pre-roll restarts env e at pre-roll turn hash(e) mod 150 (episode phases uniform over 0..149, unrelated between neighbouring envs), "
+                                    "step kernel, orders written to an [N,2,7,2] tensor; persistent rollout form, see turns_per_launch), auto-reset, obs %s "
+                                    "[N,2,105]" if args.workload == "random" else
+                                    "%d concurrent DemoMap games per GPU, on-device Cycle_BRush_Turn25 vs SwarmAgent (BASELINE config 5; both bots fused "
+                                    "into the "
+                                    "step kernel, orders written out; episodes end by BaseCapture after 84-94 turns), auto-reset, obs %s [N,2,105]")
+                                    % (n_local, args.obs_dtype),
+                       "window": "desynchronised steady state: 150-turn pre-roll restarts env e at pre-roll turn hash(e) mod 150 (episode phases uniform "
+                                 "over 0..149, unrelated between neighbouring envs), "
                                  "then 150 settle turns, --warmup turns and the K timed turns",
                        "envs_per_gpu": n_local, "total_envs": total, "turns_per_launch": tpl, "turns_of_last_timed_launch": turns_last_launch,
                        "launch_form": main_form,
-                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "learner_vs_bot_per_turn": learner_leg, "learner_smart_actions_vs_bot_per_turn": smart_leg_, "pipelined_halves_per_turn": pipe_leg, "obs_float64": obs_f64, "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
+                       "one_launch_per_turn": per_turn_launch, "caller_actions_per_turn": caller_leg, "learner_vs_bot_per_turn": learner_leg,
+                       "learner_smart_actions_vs_bot_per_turn": smart_leg_, "pipelined_halves_per_turn": pipe_leg, "obs_float64": obs_f64,
+                       "without_observations": no_obs_leg, "parallelism": "env-sharded x%d" % world,
                        "kernel_source_hash": kernel_source_hash(),
                        "episodes_finished_rank0": int(st["totals"][0]),
                        "wins_p0_p1_tie_rank0": [int(x) for x in st["totals"][1:]],
@@ -817,24 +899,36 @@ def main():
         if dist_on:
             gw = list(evg.ResultGather.win_counts(gathered))
             if gw != dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"]:
-                raise SystemExit("the gathered rows (wins %s) are not what the ranks hold (sum of their own counts %s): the collective did not carry the results"
+                raise SystemExit("the gathered rows (wins %s) are not what the ranks hold (sum of their own counts %s): the collective did not carry the "
+                                 "results"
                                  % (gw, dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"]))
             try:
                 ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if args.backend == "nccl" else None
             except Exception as ex:                       # reporting only
                 ver = "unavailable (%s)" % type(ex).__name__
-            rows_per_rank = gather.rows_per_rank(gathered) if native is None else [int((gathered[a:a + c, 2] >= 0).sum()) for a, c in zip([sum(native.counts[:r]) for r in range(world)], native.counts)]
+            rows_per_rank = gather.rows_per_rank(gathered) if native is None else [int((gathered[a:a + c,
+                                                                                                 2] >= 0).sum())
+                                                                                   for a, c in zip([sum(native.counts[:r]) for r in range(world)],
+                                                                                                   native.counts)]
             out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
-                                  "collective": "one pack kernel + ONE torch.distributed.%s of [n,4] f32 episode results to rank 0 (everglades_amd.ResultGather), inside the timed region; the win-count self-check (all_reduce of 4 integers) runs after it" % gather.collective,
+                                  "collective": "one pack kernel + ONE torch.distributed.%s of [n,4] f32 episode results to rank 0 "
+                                                "(everglades_amd.ResultGather), inside the timed region; the win-count self-check (all_reduce of 4 integers) "
+                                                "runs after it" % gather.collective,
                                   "collective_us": max(p["collective_us"] for p in per_rank),
-                                  "collective_us_is": "stream time from the end of the last step launch to the end of the gather (pack kernel + gather), slowest rank, median region",
+                                  "collective_us_is": "stream time from the end of the last step launch to the end of the gather (pack kernel + gather), "
+                                                      "slowest rank, median region",
                                   "step_launches_us": max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3,
-                                  "closing_bracket": "completion of the gather (rank 0 receives every rank's rows: it cannot end before the slowest rank's steps) + torch.cuda.synchronize(); per-rank times exchanged afterwards, max over ranks",
-                                  "step_share_of_region": max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3 / (max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3 + max(p["collective_us"] for p in per_rank)),
+                                  "closing_bracket": "completion of the gather (rank 0 receives every rank's rows: it cannot end before the slowest rank's "
+                                                     "steps) + torch.cuda.synchronize(); per-rank times exchanged afterwards, max over ranks",
+                                  "step_share_of_region": max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3
+                                  / (max(p["kernel_ms_per_step"] for p in per_rank) * args.steps * 1e3 + max(p["collective_us"] for p in per_rank)),
                                   "expected": expected_if_wire_free(world, args.steps),
-                                  "collective_calls": gather.calls if native is None else repeats + 1, "collective_api": "torch.distributed" if native is None else "evg_gather_returns (RCCL through the C-ABI)", "gathered_rows": int(gathered.shape[0]), "gathered_rows_with_a_finished_episode_per_rank": rows_per_rank,
+                                  "collective_calls": gather.calls if native is None else repeats + 1,
+                                  "collective_api": "torch.distributed" if native is None else "evg_gather_returns (RCCL through the C-ABI)",
+                                  "gathered_rows": int(gathered.shape[0]), "gathered_rows_with_a_finished_episode_per_rank": rows_per_rank,
                                   "rows_expected_per_rank": gather.counts,
-                                  "gathered_wins_equal_sum_of_per_rank_counts": True, "wins_p0_p1_tie_unfinished_sum_over_ranks": dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"],
+                                  "gathered_wins_equal_sum_of_per_rank_counts": True,
+                                  "wins_p0_p1_tie_unfinished_sum_over_ranks": dist_check["wins_p0_p1_tie_unfinished_sum_over_ranks"],
                                   "per_rank": per_rank}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed)

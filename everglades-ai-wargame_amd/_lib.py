@@ -9,7 +9,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libevg.so")                # the product library; nothing in the environment changes that
 DIAG_LIB_PATH = os.path.join(HERE, "libevg_diag.so")      # `make -C csrc diag`: phase ablation, 16-envs-per-wave variant, forced IEEE division
-GRAPHS_LIB_PATH = os.path.join(HERE, "libevg_graphs.so")   # `make -C csrc graphs`: rollout launch plans replayed as library-owned hipGraphs (A/B build; measured slower)
+# `make -C csrc graphs`: rollout launch plans replayed as library-owned hipGraphs (A/B build; measured slower)
+GRAPHS_LIB_PATH = os.path.join(HERE, "libevg_graphs.so")
 STAMPS_LIB_PATH = os.path.join(HERE, "libevg_stamps.so")  # `make -C csrc stamps`: in-kernel phase stamps (tools/stamps.py)
 
 NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105
@@ -25,8 +26,13 @@ POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "al
                 "random_actions_delay", "same_commands"]      # index = EVG_POLICY_* of include/evg.h (agents/State_Machine/<name>.py)
 POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
-EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat", "evg_random_actions_seat", "evg_smart_state_seat", "evg_smart_state_compact", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war", "evg_sightings", "evg_smart_state", "evg_smart_actions", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies", "evg_scripted_actions", "evg_scripted_reset",
-           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats", "evg_episode_stats_device", "evg_pack_episode_results", "evg_pack_episode_results_counted", "evg_comm_unique_id", "evg_comm_init", "evg_gather_returns", "evg_comm_destroy", "evg_launch_plan", "evg_num_envs",
+EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat",
+           "evg_random_actions_seat", "evg_smart_state_seat", "evg_smart_state_compact", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war",
+           "evg_sightings", "evg_smart_state", "evg_smart_actions", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies",
+           "evg_scripted_actions", "evg_scripted_reset",
+           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats",
+           "evg_episode_stats_device", "evg_pack_episode_results", "evg_pack_episode_results_counted", "evg_comm_unique_id", "evg_comm_init",
+           "evg_gather_returns", "evg_comm_destroy", "evg_launch_plan", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
 
 
@@ -122,7 +128,8 @@ def load(path=None):
             raise EvgError("%s: ABI version %d, binding expects %d (an older build of the library? rebuild it)" % (path, L.evg_abi_version(), ABI_VERSION))
     missing = [n for n in EXPORTS if not hasattr(L, n)]
     if missing:       # an older build of the library (e.g. a baseline kept for tools/ab.sh): say what it lacks instead of an AttributeError
-        raise EvgError("%s does not export %s -- it was built from older sources than this binding (ABI %d); rebuild it" % (path, ", ".join(missing), ABI_VERSION))
+        raise EvgError("%s does not export %s -- it was built from older sources than this binding (ABI %d); rebuild it" % (path, ", ".join(missing),
+                                                                                                                            ABI_VERSION))
     L.evg_last_error.restype = C.c_char_p
     L.evg_abi_version.restype = C.c_int
     L.evg_default_tables.argtypes = [C.POINTER(EvgTables)]

@@ -88,7 +88,8 @@ class ResultGather:
         self.rank = dist.get_rank(group) if self.on else 0
         self.counts = [shard_range(self.total, self.world, r)[1] for r in range(self.world)]
         if self.counts[self.rank] != int(n_local):
-            raise ValueError("local shard size %d does not match shard_range(%d, %d, %d) = %d" % (int(n_local), self.total, self.world, self.rank, self.counts[self.rank]))
+            raise ValueError("local shard size %d does not match shard_range(%d, %d, %d) = %d" % (int(n_local), self.total, self.world, self.rank,
+                                                                                                  self.counts[self.rank]))
         self.width = max(self.counts)
         self.backend = str(dist.get_backend(group)).lower() if self.on else None
         if collective is None:
@@ -174,7 +175,8 @@ class NativeGather:
         self.env, self.total, self.world, self.rank, self.root = env, int(total_envs), int(world), int(rank), int(root)
         self.counts = [shard_range(self.total, self.world, r)[1] for r in range(self.world)]
         if self.counts[self.rank] != env.num_envs:
-            raise ValueError("this handle has %d envs, shard_range(%d, %d, %d) gives %d" % (env.num_envs, self.total, self.world, self.rank, self.counts[self.rank]))
+            raise ValueError("this handle has %d envs, shard_range(%d, %d, %d) gives %d" % (env.num_envs, self.total, self.world, self.rank,
+                                                                                            self.counts[self.rank]))
         if len(comm_id) != 128:
             raise ValueError("comm_id must be the 128 bytes of NativeGather.unique_id()")
         cnt = np.asarray(self.counts, np.int32)
@@ -205,7 +207,8 @@ def _refuse_poisoned(w):
     """Rows with winner -2 come from a handle whose fault word is set (evg_pack_episode_results poisons them): its results are not valid."""
     if bool((w == -2).any()):
         from ._lib import EvgFault
-        raise EvgFault("%d gathered rows are poisoned (winner -2): a rank's handle reported a chunk hand-over fault (evg_check_fault); its results are not valid" % int((w == -2).sum()))
+        raise EvgFault("%d gathered rows are poisoned (winner -2): a rank's handle reported a chunk hand-over fault (evg_check_fault); its results are not "
+                       "valid" % int((w == -2).sum()))
 
 
 def win_counts(gathered):

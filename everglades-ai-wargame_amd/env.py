@@ -90,7 +90,8 @@ class EvergladesEnv(object):
             if self._vec is not None:
                 self._vec.close()
             tables = default_tables() if (map_file is None and unit_file is None) else tables_from_json(map_file, unit_file, config_dir)
-            self._vec = EvergladesVecEnv(1, device=self._device, seed=self._seed, env_id_base=self._env_id, obs_dtype="float64", auto_reset=False, tables=tables,
+            self._vec = EvergladesVecEnv(1, device=self._device, seed=self._seed, env_id_base=self._env_id, obs_dtype="float64", auto_reset=False,
+                                         tables=tables,
                                          rng_mode="philox" if self._entropy == "philox" else "mt19937")
             if self._entropy == "mt19937":
                 self._vec.seed_stock_entropy([self._seed & 0xFFFFFFFF])

@@ -239,7 +239,8 @@ class EvergladesVecEnv(object):
         obs = self._seat_buffers()
         ms = C.c_float(0.0)
         p = self._p
-        self._check(self.L.evg_rollout_vs_policy(self._h, int(steps), int(seat), pid, self._ptr(self._actions_seat), p["obs_seat"], p["reward"], p["done"], p["winner"],
+        self._check(self.L.evg_rollout_vs_policy(self._h, int(steps), int(seat), pid, self._ptr(self._actions_seat), p["obs_seat"], p["reward"], p["done"],
+                                                 p["winner"],
                                                  p["scores"], p["status"], C.byref(ms) if time_kernel else None, self._stream()))
         out = (obs, self.reward, self.done, self._info)
         return out + (float(ms.value),) if time_kernel else out
@@ -346,7 +347,8 @@ class EvergladesVecEnv(object):
             player = -1
         else:
             self._user(obs, (self.num_envs, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
-        rc = self.L.evg_smart_actions(self._h, int(player), C.c_void_p(obs.data_ptr()), C.c_void_p(q.data_ptr()), C.c_void_p(out.data_ptr()), self._ptr(directions), self._stream())
+        rc = self.L.evg_smart_actions(self._h, int(player), C.c_void_p(obs.data_ptr()), C.c_void_p(q.data_ptr()), C.c_void_p(out.data_ptr()),
+                                      self._ptr(directions), self._stream())
         if rc:
             self._check(rc)
         return out
@@ -431,7 +433,8 @@ class EvergladesVecEnv(object):
         p1 = self.POLICIES[policy1] if isinstance(policy1, str) else int(policy1)
         if not fused and not (observe and record_actions):
             raise ValueError("observe=False / record_actions=False need the fused forms (the agents of the unfused form read self.obs)")
-        self._check(self.L.evg_rollout_policies(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p0, p1, self._ptr(self._actions) if record_actions else None,
+        self._check(self.L.evg_rollout_policies(self._h, int(steps), (max(1, int(turns_per_launch)) if fused else 0), p0, p1,
+                                                self._ptr(self._actions) if record_actions else None,
                                                self._ptr(self.obs) if observe else None, self._ptr(self.reward),
                                                self._ptr(self.done), self._ptr(self.winner), self._ptr(self.scores), self._ptr(self.status),
                                                C.byref(ms) if time_kernel else None, self._stream()))

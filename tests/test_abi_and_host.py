@@ -185,7 +185,8 @@ def test_product_library_has_no_diagnostic_hooks(evg):
     defined = subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True)
     assert "evg_diag_configure" not in defined and "evg_debug_read_stamps" not in defined
     assert "evg_step_kernelIfLi32" not in defined                  # no helper-lane instantiation of the two-lane step kernel
-    src = open(os.path.join(ROOT, "everglades-ai-wargame_amd", "_lib.py")).read() + open(os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc", "evg_abi.hip")).read()
+    src = open(os.path.join(ROOT, "everglades-ai-wargame_amd", "_lib.py")).read() + open(os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc",
+                                                                                                      "evg_abi.hip")).read()
     assert "getenv" not in src and "os.environ" not in src
     if os.path.exists(evg._lib.DIAG_LIB_PATH):
         assert "evg_diag_configure" in subprocess.check_output(["nm", "-D", "--defined-only", evg._lib.DIAG_LIB_PATH], text=True)
@@ -316,7 +317,8 @@ def test_bench_stdout_line_is_compact_and_complete():
         # (a one-rank REHEARSAL carries the single-GPU legs and the distributed block at once; a real N > 1 line has no extra legs)
         assert len(line) < (4100 if "rehearse_rccl" in f else 3600), (f, len(line))
         c = json.loads(line)
-        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                  "config", "roofline"):
             assert k in c, (f, k)
         assert abs(c["value"] / full["value"] - 1) < 1e-5 and c["metric"] == full["metric"] and "workload" in c["config"]
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -349,5 +351,6 @@ def test_bench_stdout_line_is_compact_and_complete():
     # what a first multi-GPU line is read against: N x the committed one-rank RCCL rehearsal of the same shape, next to the one-GPU line of that shape
     exp = bench.expected_if_wire_free(8, 20)
     assert exp and "r05_d_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
-    assert 0.9 < exp["weak_scaling_efficiency_if_wire_free"] < 1.0 and exp["collective_us_1rank"] > 0       # step launches / (step launches + collective path), one run
+    # step launches / (step launches + collective path), one run
+    assert 0.9 < exp["weak_scaling_efficiency_if_wire_free"] < 1.0 and exp["collective_us_1rank"] > 0
     assert bench.expected_if_wire_free(8, 12345) is None

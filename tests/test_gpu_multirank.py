@@ -103,7 +103,8 @@ def _run_ranks(tmp_path, oracle_mod, backend, world, ndev, total, seed=20261005,
     port = 29900 + os.getpid() % 300
     envv = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     # fresh processes, started before anything touches the GPU in them
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(total), str(seed), str(steps), str(tmp_path), ROOT, backend, str(ndev)], env=envv)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(total), str(seed), str(steps), str(tmp_path), ROOT, backend, str(ndev)],
+                              env=envv)
              for r in range(world)]
     # ... and meanwhile ONE oracle run over all envs (global ids 0 .. total - 1)
     oracle_mod.lib().evo_set_num_threads(min(16, len(os.sched_getaffinity(0))))
@@ -151,7 +152,9 @@ def test_one_rank_over_rccl_vs_oracle(tmp_path, oracle_mod):
     assert str(g["backend"]) == "nccl"
 
 
-@pytest.mark.skipif(_gpus() < 2, reason="needs >= 2 GPUs: one rank per GPU over RCCL / xGMI (this box has %d); the gloo and one-rank RCCL forms of the same program ran instead" % _gpus())
+@pytest.mark.skipif(_gpus() < 2,
+                    reason="needs >= 2 GPUs: one rank per GPU over RCCL / xGMI (this box has %d); the gloo and one-rank RCCL forms of the same program ran "
+                           "instead" % _gpus())
 def test_one_rank_per_gpu_over_rccl_vs_oracle(tmp_path, oracle_mod):
     """One rank per visible GPU (at most 8), backend nccl = RCCL over xGMI.  8 GPUs: BASELINE config 4 at its full size, 8 x 65 536 envs;
     fewer: uneven shards of about 20 000 envs."""

@@ -100,7 +100,9 @@ def test_random_rollout_vs_oracle(evg, oracle_mod, N):
         assert np.allclose(_np(rew), o_rew, rtol=0, atol=REWARD_ATOL)
         if t % 25 == 0 or t >= 149:
             check_state(env, ora.get_state(), t)
-            assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.knowledge()), ora.knowledge()) and np.array_equal(_np(env.sightings()), ora.sightings())
+            assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.knowledge()),
+                                                                                              ora.knowledge()) and np.array_equal(_np(env.sightings()),
+                                                                                                                                  ora.sightings())
     st, ost = env.episode_stats(), ora.episode_stats()
     assert np.array_equal(st["totals"], ost["totals"]) and np.array_equal(st["winner"], ost["winner"])
     assert np.array_equal(st["length"], ost["length"]) and np.allclose(st["returns"], ost["returns"], rtol=1e-6, atol=1e-5)
@@ -231,7 +233,8 @@ def test_full_size_properties(evg, oracle_mod):
     assert np.array_equal(o[:, 0, 0].astype(np.int64), s["env"][:, 0]) and (np.abs(o[:, :, 3:45:4]) <= 500).all()
     assert np.array_equal(o[:, 0, 49::5].astype(np.int64), cnt[:, 0]) and np.array_equal(o[:, 1, 49::5].astype(np.int64), cnt[:, 1])
     # opposing-unit columns of board_state sum to the opponent's alive units (every non-destroyed group is listed at one node)
-    assert np.array_equal(o[:, 0, 4:45:4].sum(1).astype(np.int64), cnt[:, 1].sum(1)) and np.array_equal(o[:, 1, 4:45:4].sum(1).astype(np.int64), cnt[:, 0].sum(1))
+    assert np.array_equal(o[:, 0, 4:45:4].sum(1).astype(np.int64), cnt[:, 1].sum(1)) and np.array_equal(o[:, 1, 4:45:4].sum(1).astype(np.int64),
+                                                                                                        cnt[:, 0].sum(1))
     st, ost = env.episode_stats(), ora.episode_stats()
     assert st["totals"][0] == finished.sum() and st["totals"][1:].sum() == st["totals"][0]
     assert np.array_equal(st["winner"][lo:lo + n], ost["winner"]) and np.array_equal(st["length"][lo:lo + n], ost["length"])
@@ -861,7 +864,8 @@ def test_plain_c_client_of_the_abi(evg):
     N, turns, seed = 1000, 320, 77
     out = subprocess.run([exe, str(N), str(turns), str(seed)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    f = " ".join(l for l in out.stdout.splitlines() if l.split(" ")[0] in ("envs", "vs_episodes", "gathered_rows")).split()      # (RCCL prints its version on stdout too)
+    # (RCCL prints its version on stdout too)
+    f = " ".join(l for l in out.stdout.splitlines() if l.split(" ")[0] in ("envs", "vs_episodes", "gathered_rows")).split()
     got = {f[i]: int(f[i + 1]) for i in range(0, len(f), 2)}
     env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True)
     env.reset()
@@ -882,7 +886,8 @@ def test_plain_c_client_of_the_abi(evg):
     # ... and its third part: the path's one exchange through evg_comm_init / evg_gather_returns (RCCL opened by the library, a one-rank communicator here)
     st = env.episode_stats()
     assert got["gathered_rows"] == N and got["gathered_length_sum"] == int(st["length"].sum())
-    assert [got["gathered_p0"], got["gathered_p1"], got["gathered_tie"], got["gathered_unfinished"]] == [int((st["winner"] == k).sum()) for k in (0, 1, 2)] + [int((st["winner"] < 0).sum())]
+    assert [got["gathered_p0"], got["gathered_p1"], got["gathered_tie"],
+            got["gathered_unfinished"]] == [int((st["winner"] == k).sum()) for k in (0, 1, 2)] + [int((st["winner"] < 0).sum())]
     env.close()
 
 
@@ -1001,7 +1006,8 @@ def test_custom_tables_vs_oracle(evg, oracle_mod, force_ieee_div):
             oa[:, seat] = _np(rows)
             so, _, _, info = env.step_vs(pol, rows, seat=seat)
             o_obs, _, _, o_info = ora.step(oa)
-            assert np.array_equal(_np(so).astype(np.float64), o_obs[:, seat]) and np.array_equal(_np(info["scores"]), o_info["scores"]), ("step_vs, custom tables", pol, seat, tt)
+            assert np.array_equal(_np(so).astype(np.float64), o_obs[:, seat]) and np.array_equal(_np(info["scores"]),
+                                                                                                 o_info["scores"]), ("step_vs, custom tables", pol, seat, tt)
     env.scripted_reset(); ora.scripted_reset()
     env.rollout_policies(90, "cycle_target_node11P2", "cycle_target_node", fused=True, turns_per_launch=30)
     for tt in range(90):
@@ -1082,7 +1088,8 @@ def test_ten_thousand_reference_matches_on_device(evg):
             so, rew, done, info = env.step_vs("random_actions", env.random_actions_seat(seat), seat=seat)
         st3 = env.episode_stats()
         assert int(done.sum()) == n and st3["totals"].tolist() == [n] + d["wins_p0_p1_tie"].tolist(), seat
-        assert np.array_equal(st3["winner"], d["winner"]) and np.array_equal(st3["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"]), seat
+        assert np.array_equal(st3["winner"], d["winner"]) and np.array_equal(st3["length"], d["length"]) and np.array_equal(_np(info["scores"]),
+                                                                                                                            d["scores"]), seat
         env.close()
 
 
@@ -1114,9 +1121,9 @@ def test_ten_thousand_reference_matches_config5_on_device(evg):
     st2 = env.episode_stats()
     assert np.array_equal(st2["winner"], d["winner"]) and np.array_equal(st2["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"])
     env.close()
-    # ... and through the learner-seat turn (evg_step_vs_policy), in both arrangements the reference's scripts use: the "learner" -- here the other bot's orders,
-    # computed by the standalone agent kernel from the ONE-SEAT observation tensor the turn returns -- on seat 0 with SwarmAgent inside the step kernel, and on
-    # seat 1 with Cycle_BRush_Turn25 inside.  Same 10 000 reference-played games, same winners, lengths and final scores.
+    # ... and through the learner-seat turn (evg_step_vs_policy), in both arrangements the reference's scripts use: the "learner" -- here the other bot's
+    # orders, computed by the standalone agent kernel from the ONE-SEAT observation tensor the turn returns -- on seat 0 with SwarmAgent inside the step
+    # kernel, and on seat 1 with Cycle_BRush_Turn25 inside.  Same 10 000 reference-played games, same winners, lengths and final scores.
     import torch
     for seat, learner, bot in ((0, "cycle_rush_turn25", "swarm"), (1, "swarm", "cycle_rush_turn25")):
         env = evg.EvergladesVecEnv(n, seed=int(d["seed"][0]), env_id_base=0, auto_reset=False)
@@ -1129,7 +1136,8 @@ def test_ten_thousand_reference_matches_config5_on_device(evg):
             so, rew, done, info = env.step_vs(bot, rows, seat=seat)
         st3 = env.episode_stats()
         assert int(done.sum()) == n and st3["totals"].tolist() == [n] + d["wins_p0_p1_tie"].tolist(), (seat, st3["totals"])
-        assert np.array_equal(st3["winner"], d["winner"]) and np.array_equal(st3["length"], d["length"]) and np.array_equal(_np(info["scores"]), d["scores"]), seat
+        assert np.array_equal(st3["winner"], d["winner"]) and np.array_equal(st3["length"], d["length"]) and np.array_equal(_np(info["scores"]),
+                                                                                                                            d["scores"]), seat
         env.close()
 
 
@@ -1649,7 +1657,8 @@ def test_launch_plan_follows_the_device_and_chunked_rollouts_match_oracle(evg, o
     assert probe.launch_plan(1)[0] == 1 and "single-turn" in probe.launch_plan(1)[1]
     probe.close()
     cap2, cap4a, cap4b = 32 * s2, 16 * s4a, 16 * s4b
-    for N, want in ((cap4a, ["four lanes per env, built for 2"]), (cap4a + 1, ["four lanes per env, built for 3"]), (cap4b + 1, ["two lanes per env, persistent>"]),
+    for N, want in ((cap4a, ["four lanes per env, built for 2"]), (cap4a + 1, ["four lanes per env, built for 3"]),
+                    (cap4b + 1, ["two lanes per env, persistent>"]),
                     (cap2, ["two lanes per env, persistent>"]), (2 * cap2, ["two lanes per env, persistent>[envs 0..%d:" % (2 * cap2)]),
                     (cap2 + 1, ["chunked>[envs 0..%d: %d sets of 32 envs x 6 chunks of 25 turns" % (cap2 + 1, s2 + 1)]),
                     (cap2 + cap4a, ["chunked>[envs 0..%d: %d sets of 32 envs x 6 chunks" % (cap2 + cap4a, s2 + s4a // 2)]),
@@ -1687,7 +1696,8 @@ def test_launch_plan_follows_the_device_and_chunked_rollouts_match_oracle(evg, o
                     a2 = _np(env.random_actions()).copy()
                     obs2, _, _, info2 = env.step(a2)
                     o2, _, _, oi2 = ora2.step(a2)
-                    assert np.array_equal(_np(obs2).astype(np.float64), o2) and np.array_equal(_np(info2["scores"]), oi2["scores"]), ("evg_step after a chunked launch", t)
+                    assert np.array_equal(_np(obs2).astype(np.float64), o2) and np.array_equal(_np(info2["scores"]),
+                                                                                               oi2["scores"]), ("evg_step after a chunked launch", t)
                 mask = (np.arange(N) % 7 == 0).astype(np.uint8)
                 assert np.array_equal(_np(env.reset(mask=mask)).astype(np.float64)[mask != 0], ora2.reset(mask=mask)[mask != 0])
                 check_state(env, ora2.get_state(), "after chunked launch + steps + masked reset")
@@ -1912,7 +1922,8 @@ def test_step_vs_policy_every_bot_both_seats_vs_oracle(evg, oracle_mod, pol):
         env.close()
 
 
-@pytest.mark.parametrize("pol,seat,dtype", [("swarm", 0, "float32"), ("cycle_rush_turn25", 1, "float32"), ("swarm", 1, "float64"), ("cycle_rush_turn25", 0, "int16")])
+@pytest.mark.parametrize("pol,seat,dtype",
+                         [("swarm", 0, "float32"), ("cycle_rush_turn25", 1, "float32"), ("swarm", 1, "float64"), ("cycle_rush_turn25", 0, "int16")])
 def test_step_vs_policy_whole_batch_vs_oracle(evg, oracle_mod, pol, seat, dtype):
     """evg_step_vs_policy at the headline size: 65 536 envs + a ragged tail, 200 turns with auto-reset, the caller's orders from the
     on-device generator (evg_random_actions_seat == the seat's rows of evg_random_actions); every env's state incl. float64 health, the

@@ -3,9 +3,11 @@ selecting the step-kernel dispatches of the TIMED window (the last 150 turns of 
 warm-up launches before them are not part of any reported figure)."""
 import csv, glob, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FORMS = {"persistent": ("true, false>", 150, 1), "perturn": ("false, false>", 1, 150),     # kernel-name tail, turns per launch, step launches in the timed window
+# kernel-name tail, turns per launch, step launches in the timed window
+FORMS = {"persistent": ("true, false>", 150, 1), "perturn": ("false, false>", 1, 150),
          "caller": ("false, false>", 1, 150),    # caller-supplied orders: per turn the action kernel(s) + the single-turn step kernel
-         "learner": ("false, false>", 1, 150)}   # learner seat: per turn evg_random_actions_seat + the one-seat instantiation of the single-turn step kernel (evg_step_vs_policy)
+         # learner seat: per turn evg_random_actions_seat + the one-seat instantiation of the single-turn step kernel (evg_step_vs_policy)
+         "learner": ("false, false>", 1, 150)}
 FORM_KEY = {"persistent": "persistent", "perturn": "one_launch_per_turn", "caller": "caller_actions_per_turn", "learner": "learner_vs_bot_per_turn"}
 TWO_KERNEL_FORMS = ("caller", "learner")
 ACTION_KERNELS = ("evg_random_actions_kernel", "evg_scripted_actions_kernel")
@@ -33,7 +35,8 @@ def step_kernel(name, form):
     if form in TWO_KERNEL_FORMS and any(k in name for k in ACTION_KERNELS):
         return True
     import re
-    # evg_step_kernel<OT, 64, MULTI, MT, CHUNKED, SEAT>: the keyed-draw instantiations (MT = false) of the form's MULTI, plain or chunked; the learner form runs SEAT = true
+    # evg_step_kernel<OT, 64, MULTI, MT, CHUNKED, SEAT>: the keyed-draw instantiations (MT = false) of the form's MULTI, plain or chunked; the learner form
+    # runs SEAT = true
     if form == "learner":
         return re.search(r"evg_step_kernel<%s, 64, false, false, false, true(, 1)?>" % dtype, name) is not None
     # (round 5: a seventh template parameter, wavefronts per workgroup -- 1 in every product instantiation)
@@ -52,7 +55,8 @@ def counter_rows(directory, form):
             continue
         did = int(r["Dispatch_Id"])
         per.setdefault(did, {})[r["Counter_Name"]] = float(r["Counter_Value"])
-        meta[did] = dict(ns=int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), grid=int(r["Grid_Size"]), vgpr=int(r["VGPR_Count"]), agpr=int(r["Accum_VGPR_Count"]),
+        meta[did] = dict(ns=int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), grid=int(r["Grid_Size"]), vgpr=int(r["VGPR_Count"]),
+                         agpr=int(r["Accum_VGPR_Count"]),
                          sgpr=int(r["SGPR_Count"]), lds=int(r["LDS_Block_Size"]), scratch=int(r["Scratch_Size"]), name=r["Kernel_Name"])
     ids = sorted(per)
     return [per[i] for i in ids], [meta[i] for i in ids]
@@ -71,5 +75,6 @@ def kernels_per_turn(form):
 def trace_durations(directory, form):
     """durations (ns) of the step kernel's dispatches, in dispatch order, from a --kernel-trace CSV"""
     f = glob.glob(os.path.join(directory, "*", "*_kernel_trace.csv"))[0]
-    rows = [(int(r["Dispatch_Id"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if step_kernel(r["Kernel_Name"], form)]
+    rows = [(int(r["Dispatch_Id"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if step_kernel(r["Kernel_Name"],
+                                                                                                                                         form)]
     return [d for _, d in sorted(rows)]

@@ -12,61 +12,90 @@ def leg(d, k):
     l = d["config"][k]
     return l["env_steps_per_s"] / 1e9, l["ms_per_step"] * 1e3, l["kernel_ms"] * 1e3, (l.get("roofline") or {}).get("frac")
 rows = []
-rows.append("* env-steps/s, persistent rollout form, default 450 timed turns (median of %d regions) — **%.2f G** (%.2f µs/turn; regions %.2f–%.2f G) [`%s_bench_final.json`]"
+rows.append("* env-steps/s, persistent rollout form, default 450 timed turns (median of %d regions) — **%.2f G** (%.2f µs/turn; regions %.2f–%.2f G) "
+            "[`%s_bench_final.json`]"
             % (fin["timing"]["repeats"], G(fin), fin["ms_per_step"] * 1e3, fin["timing"]["min_value"] / 1e9, fin["timing"]["max_value"] / 1e9, NAME))
-rows.append("* the driver's shape `--steps 20 --warmup 5` (median of %d regions) — **%.2f G** (%.2f µs/step, kernel %.2f µs/turn; regions %.2f–%.2f G) [`%s_bench_driver_shape.json`]"
-            % (drv["timing"]["repeats"], G(drv), drv["ms_per_step"] * 1e3, drv["roofline"]["kernel_ms"] * 1e3, drv["timing"]["min_value"] / 1e9, drv["timing"]["max_value"] / 1e9, NAME))
+rows.append("* the driver's shape `--steps 20 --warmup 5` (median of %d regions) — **%.2f G** (%.2f µs/step, kernel %.2f µs/turn; regions %.2f–%.2f G) "
+            "[`%s_bench_driver_shape.json`]"
+            % (drv["timing"]["repeats"], G(drv), drv["ms_per_step"] * 1e3, drv["roofline"]["kernel_ms"] * 1e3, drv["timing"]["min_value"] / 1e9,
+               drv["timing"]["max_value"] / 1e9, NAME))
 # the default command under rocprofv3, with the shader clock of every dispatch
 import re
 dr = open(os.path.join(ROOT, "profiles", NAME + "_default_run_kernel_stats.csv")).read().splitlines()
 m = re.search(r"median (\d+) us = ([\d.]+) us per turn.*roofline.kernel_ms = ([\d.]+)", dr[2])
 clk = [(float(a), float(b)) for a, b in re.findall(r"(\d+)@([\d.]+)", dr[4])]
 slow, fast = max(clk), min(clk)
-rows.append("* the default command under rocprofv3 — median timed region %s µs per turn (the line of that run: %.2f); a 150-turn dispatch lasts %.2f ms at %.2f GHz and %.2f ms at %.2f GHz "
+rows.append("* the default command under rocprofv3 — median timed region %s µs per turn (the line of that run: %.2f); a 150-turn dispatch lasts %.2f ms at "
+            "%.2f GHz and %.2f ms at %.2f GHz "
             "(GRBM_GUI_ACTIVE): %.2f and %.2f M shader cycles — the time follows the clock [`%s_default_run_kernel_stats.csv`]"
             % (m.group(2), float(m.group(3)) * 1e3, slow[0] / 1e3, slow[1], fast[0] / 1e3, fast[1], slow[0] * slow[1] / 1e3, fast[0] * fast[1] / 1e3, NAME))
 cw = [l for l in open(os.path.join(ROOT, "profiles", NAME + "_clock_warmup_ab.txt")).read().splitlines() if not l.startswith("#")]
 gv = lambda l: float(re.search(r"([\d.]+) G env-steps/s", l).group(1))
-rows.append("* without the clock warm-up (`--clock-warmup-ms 0`, what earlier rounds measured), same box, back to back — driver shape %.2f G against %.2f G, default %.2f G against %.2f G "
+rows.append("* without the clock warm-up (`--clock-warmup-ms 0`, what earlier rounds measured), same box, back to back — driver shape %.2f G against %.2f G, "
+            "default %.2f G against %.2f G "
             "[`%s_clock_warmup_ab.txt`]" % (gv(cw[0]), gv(cw[1]), gv(cw[2]), gv(cw[3]), NAME))
-for k, nm, both in (("one_launch_per_turn", "one launch per turn, orders drawn in the kernel", "kernel alone"), ("caller_actions_per_turn", "one launch per turn, orders from a caller tensor (the Gym consumer)", "both kernels of the turn"),
+for k, nm, both in (("one_launch_per_turn", "one launch per turn, orders drawn in the kernel", "kernel alone"),
+                    ("caller_actions_per_turn", "one launch per turn, orders from a caller tensor (the Gym consumer)", "both kernels of the turn"),
                     ("learner_vs_bot_per_turn", "learner seat vs on-device bot (`evg_step_vs_policy`, stand-in policy)", "both kernels of the turn")):
     g, ms, km, fr = leg(fin, k)
-    rows.append("* %s — %.2f G; %.1f µs wall, %.1f µs stream per turn; %s %.1f µs (rocprofv3); fabric frac %.2f [`%s_bench_final.json`, `%s_kernel_stats.csv`]" % (nm, g, ms, km, both, pm[k]["kernel_us_per_turn"], fr, NAME, NAME))
+    rows.append("* %s — %.2f G; %.1f µs wall, %.1f µs stream per turn; %s %.1f µs (rocprofv3); fabric frac %.2f [`%s_bench_final.json`, "
+                "`%s_kernel_stats.csv`]" % (nm, g, ms, km, both, pm[k]["kernel_us_per_turn"], fr, NAME, NAME))
 s = fin["config"]["learner_smart_actions_vs_bot_per_turn"]
-rows.append("* the same with `evg_smart_actions` as the learner's decode; + `evg_smart_state_compact` in front — %.2f G, %.1f µs stream per turn; %.2f G, %.1f µs [`%s_bench_final.json`]"
+rows.append("* the same with `evg_smart_actions` as the learner's decode; + `evg_smart_state_compact` in front — %.2f G, %.1f µs stream per turn; %.2f G, "
+            "%.1f µs [`%s_bench_final.json`]"
             % (s["env_steps_per_s"] / 1e9, s["kernel_ms"] * 1e3, s["with_features"]["env_steps_per_s"] / 1e9, s["with_features"]["kernel_ms"] * 1e3, NAME))
 p = fin["config"]["pipelined_halves_per_turn"]
-rows.append("* two half-batch handles free-running (`PipelinedVecEnv`) — %.2f G; %.1f µs wall, %.1f µs stream per turn of the whole batch (learner-seat turn: %.1f µs) [`%s_bench_final.json`]"
+rows.append("* two half-batch handles free-running (`PipelinedVecEnv`) — %.2f G; %.1f µs wall, %.1f µs stream per turn of the whole batch (learner-seat "
+            "turn: %.1f µs) [`%s_bench_final.json`]"
             % (p["env_steps_per_s"] / 1e9, p["ms_per_step"] * 1e3, p["kernel_ms"] * 1e3, p["learner_vs_bot"]["kernel_ms"] * 1e3, NAME))
 n, o = fin["config"]["without_observations"], fin["config"]["obs_float64"]
-rows.append("* persistent without observations / with float64 observations / int16 — %.2f G (%.1f µs) / %.2f G (%.1f µs) / %.2f G (%.1f µs) [`%s_bench_final.json`, `%s_bench_int16.json`]"
-            % (n["env_steps_per_s"] / 1e9, n["ms_per_step"] * 1e3, o["env_steps_per_s"] / 1e9, o["ms_per_step"] * 1e3, G(i16), i16["ms_per_step"] * 1e3, NAME, NAME))
+rows.append("* persistent without observations / with float64 observations / int16 — %.2f G (%.1f µs) / %.2f G (%.1f µs) / %.2f G (%.1f µs) "
+            "[`%s_bench_final.json`, `%s_bench_int16.json`]"
+            % (n["env_steps_per_s"] / 1e9, n["ms_per_step"] * 1e3, o["env_steps_per_s"] / 1e9, o["ms_per_step"] * 1e3, G(i16), i16["ms_per_step"] * 1e3, NAME,
+               NAME))
 r = fin["roofline"]
-rows.append("* roofline (bound `fabric`): bytes per env-step, rate, fraction of 8 TB/s — persistent %.0f B → %.2f TB/s = **%.2f** at the live kernel time (%.2f at rocprofv3's %.2f µs); one launch per turn %.0f B → **%.2f**; "
+rows.append("* roofline (bound `fabric`): bytes per env-step, rate, fraction of 8 TB/s — persistent %.0f B → %.2f TB/s = **%.2f** at the live kernel time "
+            "(%.2f at rocprofv3's %.2f µs); one launch per turn %.0f B → **%.2f**; "
             "caller orders %.0f B → **%.2f**; learner seat %.0f B → **%.2f**; driver shape **%.2f** [`%s_pmc_traffic.json`, bench lines]"
-            % (r["bytes_per_env_step"], r["achieved"] / 1e3, r["frac"], pm["persistent"]["frac_of_8TBps"], pm["persistent"]["kernel_us_per_turn"], pm["one_launch_per_turn"]["bytes_per_env_step"], pm["one_launch_per_turn"]["frac_of_8TBps"],
-               pm["caller_actions_per_turn"]["bytes_per_env_step"], pm["caller_actions_per_turn"]["frac_of_8TBps"], pm["learner_vs_bot_per_turn"]["bytes_per_env_step"], pm["learner_vs_bot_per_turn"]["frac_of_8TBps"], drv["roofline"]["frac"], NAME))
+            % (r["bytes_per_env_step"], r["achieved"] / 1e3, r["frac"], pm["persistent"]["frac_of_8TBps"], pm["persistent"]["kernel_us_per_turn"],
+               pm["one_launch_per_turn"]["bytes_per_env_step"], pm["one_launch_per_turn"]["frac_of_8TBps"],
+               pm["caller_actions_per_turn"]["bytes_per_env_step"], pm["caller_actions_per_turn"]["frac_of_8TBps"],
+               pm["learner_vs_bot_per_turn"]["bytes_per_env_step"], pm["learner_vs_bot_per_turn"]["frac_of_8TBps"], drv["roofline"]["frac"], NAME))
 if r.get("algorithmic_bytes_per_env_step"):
-    rows.append("* algorithmic bytes of this design / counter bytes — %.0f B (971 B of outputs + 2 × %.0f B of health rows) / %.0f B: `traffic_over_algorithmic` %.2f [`%s_bench_final.json`]"
-                % (r["algorithmic_bytes_per_env_step"], (r["algorithmic_bytes_per_env_step"] - 971) / 2, r["bytes_per_env_step"], r["traffic_over_algorithmic"], NAME))
+    rows.append("* algorithmic bytes of this design / counter bytes — %.0f B (971 B of outputs + 2 × %.0f B of health rows) / %.0f B: "
+                "`traffic_over_algorithmic` %.2f [`%s_bench_final.json`]"
+                % (r["algorithmic_bytes_per_env_step"], (r["algorithmic_bytes_per_env_step"] - 971) / 2, r["bytes_per_env_step"],
+                   r["traffic_over_algorithmic"], NAME))
 b = r["beyond_mall"]
 dg, pc, wr = b["diag_library_chunked_over_262144_envs"], b["product_library_chunked_over_131071_envs_cache_mib_1024"], b["whole_rounds_one_after_the_other"]["persistent"]
-rows.append("* **`hbm_proper_frac`**: the persistent kernel cycled through %d MB (diagnostic library, 262 144 envs) — %.0f B, %.3f ns per env-step (%.3f at 65 536), %.2f TB/s = **%.2f of the HBM peak** [`%s`]"
-            % (dg["working_set_MB"], dg["bytes_per_env_step"], dg["ns_per_env_step"], dg["ns_per_env_step_at_65536"], dg["traffic_TBps"], dg["frac_of_8TBps"], os.path.basename(dg["source"])))
-rows.append("* the product library cycled through %d MB (131 071 envs, `cache_mib` 1 024) / the product's whole rounds at 262 144 envs — %.2f (%.3f ns per env-step: 1.35 × the cache is still mostly cache-resident) / %.2f (%.3f ns) [`%s`, `%s`]"
-            % (pc["working_set_MB"], pc["frac_of_8TBps"], pc["ns_per_env_step"], wr["frac_of_8TBps"], wr["ns_per_env_step"], os.path.basename(pc["source"]), os.path.basename(wr["source"])))
-rows.append("* `survey_8d_frac` (4 530 B per env-step at the kernel time) — %.2f (default), %.2f (driver shape): above 1, model not applicable [bench lines]" % (r["survey_8d_frac"], drv["roofline"]["survey_8d_frac"]))
+rows.append("* **`hbm_proper_frac`**: the persistent kernel cycled through %d MB (diagnostic library, 262 144 envs) — %.0f B, %.3f ns per env-step (%.3f at "
+            "65 536), %.2f TB/s = **%.2f of the HBM peak** [`%s`]"
+            % (dg["working_set_MB"], dg["bytes_per_env_step"], dg["ns_per_env_step"], dg["ns_per_env_step_at_65536"], dg["traffic_TBps"], dg["frac_of_8TBps"],
+               os.path.basename(dg["source"])))
+rows.append("* the product library cycled through %d MB (131 071 envs, `cache_mib` 1 024) / the product's whole rounds at 262 144 envs — %.2f (%.3f ns per "
+            "env-step: 1.35 × the cache is still mostly cache-resident) / %.2f (%.3f ns) [`%s`, `%s`]"
+            % (pc["working_set_MB"], pc["frac_of_8TBps"], pc["ns_per_env_step"], wr["frac_of_8TBps"], wr["ns_per_env_step"], os.path.basename(pc["source"]),
+               os.path.basename(wr["source"])))
+rows.append("* `survey_8d_frac` (4 530 B per env-step at the kernel time) — %.2f (default), %.2f (driver shape): above 1, model not applicable [bench lines]"
+            % (r["survey_8d_frac"], drv["roofline"]["survey_8d_frac"]))
 v = fin["roofline_valu_issue"]
-rows.append("* `roofline_valu_issue` — %.0f VALU instructions per wave-turn → **%.2f** of one wave64 instruction per 4 cycles per SIMD at 2.4 GHz [`%s`]" % (v["valu_insts_per_wave_turn"], v["frac"], os.path.basename(v["source"])))
+rows.append("* `roofline_valu_issue` — %.0f VALU instructions per wave-turn → **%.2f** of one wave64 instruction per 4 cycles per SIMD at 2.4 GHz [`%s`]"
+            % (v["valu_insts_per_wave_turn"], v["frac"], os.path.basename(v["source"])))
 cb = fin["cpu_baseline"]
-rows.append("* cpu_baseline (C oracle, OpenMP, %d cores of the GPU box, f64 observations) — %.1f M env-steps/s; the same 65 536 games × %d turns replayed: episode results, win counts %s and final state incl. float64 health equal: %s [`%s_bench_final.json`, `kind: \"port\"`]"
-            % (cb["cores"], cb["value"] / 1e6, cb["same_games_as_gpu"]["turns"], cb["same_games_as_gpu"]["gpu_wins_p0_p1_tie"], cb["same_games_as_gpu"]["equal"], NAME))
+rows.append("* cpu_baseline (C oracle, OpenMP, %d cores of the GPU box, f64 observations) — %.1f M env-steps/s; the same 65 536 games × %d turns replayed: "
+            "episode results, win counts %s and final state incl. float64 health equal: %s [`%s_bench_final.json`, `kind: \"port\"`]"
+            % (cb["cores"], cb["value"] / 1e6, cb["same_games_as_gpu"]["turns"], cb["same_games_as_gpu"]["gpu_wins_p0_p1_tie"],
+               cb["same_games_as_gpu"]["equal"], NAME))
 rows.append("* Python reference, 1 core / 8 cores (build container) — 529–554 / 3 208 env-steps/s [BASELINE.md]")
-rows.append("* BASELINE config 5 (Cycle_BRush_Turn25 vs SwarmAgent fused, 65 536 envs) — **%.2f G** (%.1f µs/turn), %.0f B → frac %.2f [`%s_bench_config5.json`, `%s_config5_pmc_traffic.json`]" % (G(c5), c5["ms_per_step"] * 1e3, c5["roofline"]["bytes_per_env_step"], c5["roofline"]["frac"], NAME, NAME))
-rows.append("* BASELINE config 2 (4 096 envs; four-lane kernel; working set in L2 / Infinity Cache: latency-bound, `frac` meaningless) — **%.0f M** (%.1f µs/turn) [`%s_bench_4096envs.json`]" % (G(k4) * 1e3, k4["ms_per_step"] * 1e3, NAME))
+rows.append("* BASELINE config 5 (Cycle_BRush_Turn25 vs SwarmAgent fused, 65 536 envs) — **%.2f G** (%.1f µs/turn), %.0f B → frac %.2f "
+            "[`%s_bench_config5.json`, `%s_config5_pmc_traffic.json`]" % (G(c5), c5["ms_per_step"] * 1e3, c5["roofline"]["bytes_per_env_step"],
+                                                                          c5["roofline"]["frac"], NAME, NAME))
+rows.append("* BASELINE config 2 (4 096 envs; four-lane kernel; working set in L2 / Infinity Cache: latency-bound, `frac` meaningless) — **%.0f M** (%.1f "
+            "µs/turn) [`%s_bench_4096envs.json`]" % (G(k4) * 1e3, k4["ms_per_step"] * 1e3, NAME))
 d = rc["distributed"]
-rows.append("* N > 1 code path, RCCL with a one-rank group, `--steps 20` — %.2f G; step launches %.0f µs + collective path (pack + gather) **%.1f µs** → `step_share_of_region` %.3f [`%s_bench_rehearse_rccl_1rank.json`]"
+rows.append("* N > 1 code path, RCCL with a one-rank group, `--steps 20` — %.2f G; step launches %.0f µs + collective path (pack + gather) **%.1f µs** → "
+            "`step_share_of_region` %.3f [`%s_bench_rehearse_rccl_1rank.json`]"
             % (G(rc), d["step_launches_us"], d["collective_us"], d["step_share_of_region"], NAME))
-rows.append("* N > 1 code path, two ranks over gloo sharing the one GPU — %.2f G for 131 072 envs (host-copy collective %.0f µs): plumbing only [`%s_bench_rehearse_gloo_2ranks_one_gpu.json`]" % (G(gl), gl["distributed"]["collective_us"], NAME))
+rows.append("* N > 1 code path, two ranks over gloo sharing the one GPU — %.2f G for 131 072 envs (host-copy collective %.0f µs): plumbing only "
+            "[`%s_bench_rehearse_gloo_2ranks_one_gpu.json`]" % (G(gl), gl["distributed"]["collective_us"], NAME))
 print("\n".join(rows))

@@ -31,8 +31,10 @@ def calib(sub):
 calib_f, calib_w = calib("calib_fetch"), calib("calib_write")
 fetch_scale, write_scale = 262144.0 / calib_f, 262144.0 / calib_w            # expected KB / reported
 out = {"kernel_source_hash": kernel_source_hash(), "envs": ENVS, "workload": WORKLOAD, "obs_dtype": OBS, "variant": VARIANT,
-       "commands": {f: open(os.path.join(P, "cmd_%s.txt" % f)).read().strip().replace(ROOT + "/", "").replace(os.environ.get("GRAFT_REPO_ROOT", "\0") + "/", "") for f in FORMS},
-       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; bytes = FETCH_SIZE KB x fetch_scale + WRITE_SIZE KB x write_scale "
+       "commands": {f: open(os.path.join(P, "cmd_%s.txt" % f)).read().strip().replace(ROOT + "/", "").replace(os.environ.get("GRAFT_REPO_ROOT", "\0") + "/",
+                                                                                                              "") for f in FORMS},
+       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; bytes = FETCH_SIZE KB x fetch_scale + WRITE_SIZE KB x "
+                 "write_scale "
                  "(the gfx950 correction of MI355X_MICROARCH.md, re-derived by the calibration copy in the same passes); dispatches of the timed window only "
                  "(desynchronised steady state, bench.py docstring)",
        "calibration": {"copy_256MiB_FETCH_SIZE_KB": calib_f, "copy_256MiB_WRITE_SIZE_KB": calib_w, "expected_KB": 262144,
@@ -45,7 +47,8 @@ for form, (tail, tpl, nwin) in FORMS.items():
     f_kb = [r["FETCH_SIZE"] for r in timed_window(fr, form)]
     w_kb = [r["WRITE_SIZE"] for r in timed_window(wr, form)]
     dur = timed_window(trace_durations(os.path.join(P, form + "_stats"), form), form)
-    kpt = _prof.kernels_per_turn(form)                               # dispatches per launch unit (caller / learner forms: action kernel(s) + step kernel = one turn)
+    # dispatches per launch unit (caller / learner forms: action kernel(s) + step kernel = one turn)
+    kpt = _prof.kernels_per_turn(form)
     per_launch = (sum(f_kb) / len(f_kb) * round(fetch_scale) + sum(w_kb) / len(w_kb) * round(write_scale)) * 1024.0 * kpt
     mean_ns = sum(dur) / len(dur) * kpt
     bpe = per_launch / tpl / ENVS
@@ -58,13 +61,15 @@ for form, (tail, tpl, nwin) in FORMS.items():
                                     "traffic_TBps": per_launch / mean_ns / 1e3, "frac_of_8TBps": per_launch / mean_ns / 1e3 / 8.0,
                                     "kernels_per_turn": kpt,
                                     "vgpr_allocated": 2 * fm[-1]["vgpr"], "vgpr_rocprofv3_column": fm[-1]["vgpr"],
-                                    "vgpr_note": "rocprofv3's VGPR_Count column counts in units of two registers on gfx950: the value printed is half of the allocation, which is the "
+                                    "vgpr_note": "rocprofv3's VGPR_Count column counts in units of two registers on gfx950: the value printed is half of the "
+                                                 "allocation, which is the "
                                                  "compiler's count (make resource-usage) rounded up to the allocation granule of 8",
                                     "agpr": fm[-1]["agpr"], "sgpr": fm[-1]["sgpr"], "lds_bytes": fm[-1]["lds"], "scratch": fm[-1]["scratch"]}
     src = glob.glob(os.path.join(P, form + "_stats", "*", "*_kernel_stats.csv"))[0]
     lines = open(src).read().splitlines()
     stats_lines.append('"# %s  --  rocprofv3 --kernel-trace --stats --output-format csv -- %s"' % (FORM_KEY[form], out["commands"][form]))
-    stats_lines.append('"# step kernel, dispatches of the timed window only (last %d of %d): mean %.1f ns = %.2f us per turn; the --stats row below averages ALL '
+    stats_lines.append('"# step kernel, dispatches of the timed window only (last %d of %d): mean %.1f ns = %.2f us per turn; the --stats row below averages '
+                       'ALL '
                        'dispatches of the run, incl. the 150 one-turn launches of the desynchronising pre-roll (synchronised early-episode positions)"'
                        % (len(dur), len(trace_durations(os.path.join(P, form + "_stats"), form)), mean_ns, mean_ns / tpl / 1e3))
     stats_lines += [lines[0]] + [l for l in lines[1:] if "evg::" in l]

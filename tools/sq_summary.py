@@ -15,13 +15,15 @@ P = os.path.join(ROOT, "gpurun_out", "sq_" + tag)
 out = {"kernel_source_hash": kernel_source_hash(), "envs": ENVS, "workload": WORKLOAD, "obs_dtype": OBS,
        "commands": {f: open(os.path.join(P, "cmd_%s.txt" % f)).read().strip() for f in FORMS if os.path.exists(os.path.join(P, "cmd_%s.txt" % f))},
        "note": "rocprofv3 --kernel-trace --pmc <8 SQ counters per pass>; dispatches of the timed window only.  SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_* and "
-               "SQ_ACTIVE_INST_* tick in quad-cycles (MI355X_MICROARCH.md); instruction counters count wave-instructions.  per_wave_turn = per dispatch / waves / "
+               "SQ_ACTIVE_INST_* tick in quad-cycles (MI355X_MICROARCH.md); instruction counters count wave-instructions.  per_wave_turn = per dispatch / "
+               "waves / "
                "turns of the dispatch.", "kernels": {}}
 for form, (tail, tpl, nwin) in FORMS.items():
     mean, meta = {}, None
     for d in sorted(x for x in glob.glob(os.path.join(P, form + "_p*")) if os.path.isdir(x)):
         rows, m = counter_rows(d, form)
-        keep = [i for i, x in enumerate(m) if not any(k in x["name"] for k in _prof.ACTION_KERNELS)]      # the step kernel only (two-kernel forms list the action kernel too)
+        # the step kernel only (two-kernel forms list the action kernel too)
+        keep = [i for i, x in enumerate(m) if not any(k in x["name"] for k in _prof.ACTION_KERNELS)]
         rows, m = [rows[i] for i in keep], [m[i] for i in keep]
         rows = rows[-FORMS[form][2]:]
         meta = m[-1]
@@ -33,7 +35,8 @@ for form, (tail, tpl, nwin) in FORMS.items():
     ns = mean.pop("_ns")
     waves = meta["grid"] // 64
     pw = {c: v / waves / tpl for c, v in mean.items()}
-    e = {"kernel": meta["name"], "waves": waves, "turns_per_launch": tpl, "vgpr": meta["vgpr"], "agpr": meta["agpr"], "sgpr": meta["sgpr"], "lds_bytes": meta["lds"],
+    e = {"kernel": meta["name"], "waves": waves, "turns_per_launch": tpl, "vgpr": meta["vgpr"], "agpr": meta["agpr"], "sgpr": meta["sgpr"],
+         "lds_bytes": meta["lds"],
          "scratch": meta["scratch"], "dispatch_ns_under_pmc": sum(ns) / len(ns), "per_wave_turn": pw}
     if "SQ_WAVE_CYCLES" in pw and "SQ_INSTS_VALU" in pw:
         e.update({"wave_cycles_per_wave_turn": 4 * pw["SQ_WAVE_CYCLES"], "valu_insts_per_wave_turn": pw["SQ_INSTS_VALU"],

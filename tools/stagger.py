@@ -20,5 +20,6 @@ for a, b, h in [(a_, 0, 0) for a_ in SWEEP]:   # delay = slot x (a - 1) + simd x
     torch.cuda.synchronize()
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record(); env.rollout_random(300); t1.record(); torch.cuda.synchronize()
-    print("stagger slot x (%2d - 1) + simd x %2d (x 64 cycles): stream time %s us per launch (160 launches each); 300 launches back to back: %.2f us per turn" % (a, b, ["%.2f" % r for r in res], t0.elapsed_time(t1) / 300 * 1e3), flush=True)
+    print("stagger slot x (%2d - 1) + simd x %2d (x 64 cycles): stream time %s us per launch (160 launches each); 300 launches back to back: %.2f us per turn"
+          % (a, b, ["%.2f" % r for r in res], t0.elapsed_time(t1) / 300 * 1e3), flush=True)
     env.close()

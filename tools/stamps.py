@@ -37,7 +37,8 @@ for upto in ((20, 50, 80) if SCRIPTED else (20, 80, 140)):
     d = np.diff(st[:, :14], axis=1)
     tot = st[:, 13] - st[:, 0]
     span = int(st[:, 13].max() - st[:, 0].min())
-    print("turn %d: mean wave %.0f cycles (max %.0f), first-start to last-end %d cycles (memtime ticks, 100 MHz => x10 ns)" % (upto, tot.mean(), tot.max(), span))
+    print("turn %d: mean wave %.0f cycles (max %.0f), first-start to last-end %d cycles (memtime ticks, 100 MHz => x10 ns)" % (upto, tot.mean(), tot.max(),
+                                                                                                                               span))
     for i, nm in enumerate(NAMES):
         print("   %-20s mean %8.0f  max %8.0f  (%4.1f%%)" % (nm, d[:, i].mean(), d[:, i].max(), 100.0 * d[:, i].mean() / tot.mean()))
 env.close()

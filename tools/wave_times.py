@@ -35,7 +35,8 @@ for rep in range(3):
     start = (t0 - t0.min()) * 10.0 / 1e3
     end = (t1 - t0.min()) * 10.0 / 1e3
     wave_id, simd, pipe, cu, sh, se = hw & 15, (hw >> 4) & 3, (hw >> 6) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
-    print("launch of %d turns: HIP-event time %.1f us; per-wave duration mean %.1f  min %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us; last start %.1f us, last end %.1f us"
+    print("launch of %d turns: HIP-event time %.1f us; per-wave duration mean %.1f  min %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us; last start %.1f us, "
+          "last end %.1f us"
           % (TURNS, ms * 1e3, dur.mean(), dur.min(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), dur.max(), start.max(), end.max()))
     print("   wave END times: p10 %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f us" % tuple(np.percentile(end, q) for q in (10, 50, 90, 99, 100)))
     print("   by XCD: " + "  ".join("%d: n=%d mean %.0f max %.0f" % (x, (xcc == x).sum(), dur[xcc == x].mean(), dur[xcc == x].max()) for x in sorted(set(xcc))))
@@ -61,5 +62,6 @@ for rep in range(3):
     for i, k in enumerate(key):
         cu_mean.setdefault(int(k), []).append(dur[i])
     cm = np.array([np.mean(v) for v in cu_mean.values()])
-    print("   per-CU mean duration: min %.1f  p50 %.1f  max %.1f us; waves per CU histogram %s" % (cm.min(), np.percentile(cm, 50), cm.max(), np.bincount([len(v) for v in cu_mean.values()]).tolist()))
+    print("   per-CU mean duration: min %.1f  p50 %.1f  max %.1f us; waves per CU histogram %s" % (cm.min(), np.percentile(cm, 50), cm.max(),
+                                                                                                   np.bincount([len(v) for v in cu_mean.values()]).tolist()))
 env.close()
