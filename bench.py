@@ -305,7 +305,8 @@ def compact_line(full):
         out["timing"] = {"repeats": t["repeats"], "reported": t["reported"], "min_ms_per_step": _r(t["min_ms_per_step"], 5),
                          "max_ms_per_step": _r(t["max_ms_per_step"], 5),
                          "min_value": _r(t["min_value"], 5), "max_value": _r(t["max_value"], 5),
-                         "clock_warmup_ms": _r(t.get("clock_warmup", {}).get("ms", 0.0), 3)}
+                         "clock_warmup_ms": _r(t.get("clock_warmup", {}).get("ms", 0.0), 3),
+                         "cold_value": _r((t.get("clock_warmup", {}).get("cold_region") or {}).get("value"), 5)}
     if "roofline_valu_issue" in full:
         v = full["roofline_valu_issue"]
         out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "frac", "valu_insts_per_wave_turn", "source")}
@@ -489,6 +490,16 @@ def main():
     # --steps 20 --warmup 5) used to measure the governor's ramp, 14 % below what every later millisecond of a rollout gets.  A scratch handle of the same size
     # plays 150-turn rollouts for --clock-warmup-ms right before the W warm-up steps; the measured handle, its games and the W / K contract are untouched.
     clock_warmup = {"requested_ms": args.clock_warmup_ms, "ms": 0.0, "turns": 0}
+    if args.clock_warmup_ms > 0 and not dist_on and args.steps <= 2500:
+        # ... and so that the line shows what the warm-up is worth, ONE K-step region is timed before it, with the clock the process has at that moment (what
+        # earlier rounds reported as the value): same brackets, same launches, reported as timing.cold_value, never as the value
+        barrier()
+        t_c = time.perf_counter()
+        rollout(args.steps, False, args.turns_per_launch, main_fused)
+        barrier()
+        cold_s = time.perf_counter() - t_c
+        played += args.steps
+        clock_warmup["cold_region"] = {"ms_per_step": cold_s / args.steps * 1e3, "value": total * args.steps / cold_s}
     if args.clock_warmup_ms > 0:
         scratch = evg.EvergladesVecEnv(n_local, device=device, seed=args.seed + 1, env_id_base=first, obs_dtype=args.obs_dtype, auto_reset=True,
                                        library=args.library)

@@ -38,7 +38,7 @@ out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench
        '%.2f us per turn.  The line of the same run: roofline.kernel_ms = %.5f, ms_per_step = %.5f (regions min %.5f, max %.5f)"'
        % (R * L, R, L, K, " ".join("%.0f" % (x / 1e3) for x in regions), med / 1e3, med / K / 1e3, line["roofline"]["kernel_ms"], line["ms_per_step"],
           line["timing"]["min_ms_per_step"], line["timing"]["max_ms_per_step"]),
-       '"# (before them: the 150 one-turn launches and the 150-turn settle launch of the desynchronising window, the 150-turn launches of the clock warm-up on a scratch handle -- bench.py --clock-warmup-ms, reported in the line as timing.clock_warmup_ms = %s -- and the 150-turn warm-up launch)"' % line["timing"].get("clock_warmup_ms"),
+       '"# (before them: the 150 one-turn launches and the 150-turn settle launch of the desynchronising window, the three launches of the COLD region timed before the clock warm-up -- timing.cold_value --, the 150-turn launches of the clock warm-up on a scratch handle -- bench.py --clock-warmup-ms, reported in the line as timing.clock_warmup_ms = %s -- and the 150-turn warm-up launch)"' % line["timing"].get("clock_warmup_ms"),
        '"# second pass, --pmc GRBM_GUI_ACTIVE: duration (us) @ effective shader clock (GHz) of the same dispatches: %s"' % " ".join("%.0f@%.2f" % (ns / 1e3, g) for ns, g in clk),
        stats[0]] + [l for l in stats[1:] if "evg::" in l]
 open("profiles/${NAME}_default_run_kernel_stats.csv", "w").write("\n".join(out) + "\n")

@@ -26,7 +26,7 @@ out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench
        'the line of the same run says roofline.kernel_ms = %.5f (x 20 turns = %.1f us between the two stream events of its median region), ms_per_step = %.5f (min %.5f, max %.5f)"'
        % (R, R, " ".join(str(d) for d in timed), med, med / 20 / 1e3, line["roofline"]["kernel_ms"], line["roofline"]["kernel_ms"] * 20 * 1e3, line["ms_per_step"],
           (line.get("timing") or {}).get("min_ms_per_step", line["ms_per_step"]), (line.get("timing") or {}).get("max_ms_per_step", line["ms_per_step"])),
-       '"# (the others: the 150-turn settle launch of the desynchronising window, the 150-turn launches of the clock warm-up on a scratch handle -- bench.py --clock-warmup-ms -- and the 5-turn warm-up launch; under the profiler every dispatch is serialised)"',
+       '"# (the others: the 150-turn settle launch of the desynchronising window, the 20-turn COLD region timed before the clock warm-up -- timing.cold_value --, the 150-turn launches of the clock warm-up on a scratch handle -- bench.py --clock-warmup-ms -- and the 5-turn warm-up launch; under the profiler every dispatch is serialised)"',
        stats[0]] + [l for l in stats[1:] if "evg::" in l]
 open("profiles/${NAME}_driver_shape_kernel_stats.csv", "w").write("\n".join(out) + "\n")
 print("\n".join(out[:4]))
