@@ -256,9 +256,9 @@ def compact_line(full):
         if "traffic" not in o:
             o["traffic"] = None
         if r.get("bound") == "fabric":
-            o["bound_is"] = "L2<->InfinityCache/HBM requests, working set cache-resident; hbm_proper_frac: same kernel beyond the cache"
+            o["bound_is"] = "L2<->InfinityCache/HBM requests; working set cache-resident"
         if "survey_8d_frac" in o:
-            o["survey_8d_note"] = "SURVEY 8(d) 4530 B model at this kernel time; >1: not applicable, state stays on chip"
+            o["survey_8d_note"] = "4530 B model at this kernel time; >1: not applicable (state stays on chip)"
         if "note" in o:
             o["note"] = "working set cache-resident: latency/issue-bound, frac meaningless"
         bm = r.get("beyond_mall")
@@ -289,7 +289,7 @@ def compact_line(full):
     out["config"] = {"workload": "%d concurrent DemoMap games per GPU, %s, persistent rollout form, auto-reset, obs %s [N,2,105]" % (
                          c["envs_per_gpu"], "random_actions vs random_actions drawn on device" if "random_actions" in c["workload"] else
                          "on-device Cycle_BRush_Turn25 vs SwarmAgent fused into the step kernel (BASELINE config 5)", obs_name),
-                     "window": "desynchronised steady state: 150-turn pre-roll (phases hash(e) mod 150) + 150 settle turns",
+                     "window": "desynchronised: 150-turn pre-roll (phase hash(e) mod 150) + 150 settle turns",
                      **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash",
                                           "episodes_finished_rank0",
                                           "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
