@@ -29,8 +29,14 @@ rows.append("* the default command under rocprofv3 — median timed region %s µ
             "%.2f GHz and %.2f ms at %.2f GHz "
             "(GRBM_GUI_ACTIVE): %.2f and %.2f M shader cycles — the time follows the clock [`%s_default_run_kernel_stats.csv`]"
             % (m.group(2), float(m.group(3)) * 1e3, slow[0] / 1e3, slow[1], fast[0] / 1e3, fast[1], slow[0] * slow[1] / 1e3, fast[0] * fast[1] / 1e3, NAME))
+bx = os.path.join(ROOT, "profiles", NAME + "_driver_shape_boxes.txt")
+if os.path.exists(bx):
+    mm = re.search(r"Spread of the value: ([\d.]+)-([\d.]+) G = ([\d.]+) %", open(bx).read())
+    rows.append("* the driver's command in four separate gpurun calls (a fresh box each) — %.2f–%.2f G: %s %% [`%s_driver_shape_boxes.txt`]"
+                % (float(mm.group(1)), float(mm.group(2)), mm.group(3), NAME))
 cold = lambda d: d["timing"]["clock_warmup"]["cold_region"]["value"] / 1e9
-rows.append("* `timing.cold_value`, ONE K-step region timed before the clock warm-up and the W warm-up steps in the same run (what rounds 1–4 reported as the value) — driver shape %.2f G against "
+rows.append("* `timing.cold_value`, ONE K-step region timed before the clock warm-up and the W warm-up steps in the same run (what rounds 1–4 reported as "
+            "the value) — driver shape %.2f G against "
             "%.2f G, default %.2f G against %.2f G [`%s_bench_driver_shape.json`, `%s_bench_final.json`]" % (cold(drv), G(drv), cold(fin), G(fin), NAME, NAME))
 cw = [l for l in open(os.path.join(ROOT, "profiles", NAME + "_clock_warmup_ab.txt")).read().splitlines() if not l.startswith("#")]
 gv = lambda l: float(re.search(r"([\d.]+) G env-steps/s", l).group(1))
