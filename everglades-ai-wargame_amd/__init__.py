@@ -18,8 +18,18 @@ __all__ = ["EvergladesVecEnv", "PipelinedVecEnv", "EvergladesEnv", "EvgError", "
            "canonical_actions", "shard_range", "gather_episode_results", "win_counts", "ResultGather", "NativeGather", "evaluate", "evaluate_all",
            "proportion_confint_normal"]
 
-try:  # optional: same gym id as the reference (gym_everglades/__init__.py:3-6) when gym is installed
-    from gym.envs.registration import register as _register
-    _register(id="everglades-v0", entry_point="everglades_amd:EvergladesEnv")
-except Exception:
-    pass
+
+
+def _register_with_gym():
+    """The reference's gym id (gym_everglades/__init__.py:3-6: register(id='everglades-v0', entry_point=...)), so that `gym.make('everglades-v0')`
+    builds this class.  gym is optional: without it there is nothing to register (ImportError only -- any other failure of the registration is a
+    real error and propagates)."""
+    try:
+        from gym.envs.registration import register
+    except ImportError:
+        return False
+    register(id="everglades-v0", entry_point="everglades_amd:EvergladesEnv")
+    return True
+
+
+GYM_REGISTERED = _register_with_gym()

@@ -3,7 +3,7 @@
 // and enqueues the kernels of evg_kernels.hip on the caller's stream.  No CPU execution path.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>       // types and prototypes only: librccl is opened at run time (dlopen), libevg.so has no NEEDED entry for it
+#include "evg_rccl_api.h"    // the few RCCL types this file names: librccl is opened at run time (dlopen), the build needs neither its header nor the library
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -64,7 +64,14 @@ struct DeviceGuard {
 // Device buffers of the caller: the kernels read and write them with 8- and 16-byte vector accesses (observation rows 16 bytes per lane, order rows int2 /
 // uint4, rewards float2, scores int2), so every one of them must be 16-byte aligned (include/evg.h, "Conventions"; any hipMalloc / torch allocation is).
 // NULL is "not given" and passes.
+// Buffers only ever touched with 8-byte accesses (rewards float2, scores int2: one pair per env) need 8 bytes, so an odd env offset into an [N][2] tensor is
+// accepted (EVG_NEED_ALIGNED8).
 bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+bool misaligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) != 0; }
+#define EVG_NEED_ALIGNED8(p)                                                                                  \
+    do {                                                                                                      \
+        if (misaligned8(p)) return fail(EVG_ERR_INVALID, "%s must be 8-byte aligned (got %p)", #p, (const void*)(p)); \
+    } while (0)
 #define EVG_NEED_ALIGNED16(p)                                                                                 \
     do {                                                                                                      \
         if (misaligned16(p)) return fail(EVG_ERR_INVALID, "%s must be 16-byte aligned (got %p)", #p, (const void*)(p)); \
@@ -615,7 +622,7 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
              int32_t* scores_out, uint8_t* status_out, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
-    EVG_NEED_ALIGNED16(actions); EVG_NEED_ALIGNED16(obs_out); EVG_NEED_ALIGNED16(reward_out); EVG_NEED_ALIGNED16(scores_out);
+    EVG_NEED_ALIGNED16(actions); EVG_NEED_ALIGNED16(obs_out); EVG_NEED_ALIGNED8(reward_out); EVG_NEED_ALIGNED8(scores_out);
     EVG_ON_DEVICE(h);
     const StepIO io = make_io(h, actions, obs_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 0, 0, 0, nullptr);
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
@@ -638,7 +645,7 @@ int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int acti
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !obs_seat_out || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, obs_seat_out, reward_out and done_out are required");
     if (seat < 0 || seat > 1 || opponent_policy < 0 || opponent_policy >= EVG_POLICY_COUNT) return fail(EVG_ERR_INVALID, "seat / opponent_policy out of range");
-    EVG_NEED_ALIGNED16(obs_seat_out); EVG_NEED_ALIGNED16(actions); EVG_NEED_ALIGNED16(reward_out); EVG_NEED_ALIGNED16(scores_out);
+    EVG_NEED_ALIGNED16(obs_seat_out); EVG_NEED_ALIGNED16(actions); EVG_NEED_ALIGNED8(reward_out); EVG_NEED_ALIGNED8(scores_out);
     if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_step_vs_policy: keyed-Philox handles only (the stock-entropy mode has no fused bots)");
     EVG_ON_DEVICE(h);
     StepIO io = make_io(h, actions, obs_seat_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 2, opponent_policy, opponent_policy, nullptr);
@@ -783,7 +790,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
     if (prepare_only) steps = -steps;
     if (steps < 1 || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "rollout: steps >= 1, reward_out, done_out required");
     if (!actions_buf && !fused) return fail(EVG_ERR_INVALID, "rollout: actions_buf is required unless the step kernel produces the orders itself (fused >= 1)");
-    EVG_NEED_ALIGNED16(actions_buf); EVG_NEED_ALIGNED16(obs_out); EVG_NEED_ALIGNED16(reward_out); EVG_NEED_ALIGNED16(scores_out);
+    EVG_NEED_ALIGNED16(actions_buf); EVG_NEED_ALIGNED16(obs_out); EVG_NEED_ALIGNED8(reward_out); EVG_NEED_ALIGNED8(scores_out);
     EVG_ON_DEVICE(h);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipStream_t s_ = s;
@@ -869,7 +876,7 @@ int evg_rollout_vs_policy(evg_handle* h, int steps, int seat, int opponent_polic
     if (steps < 1 || !actions_seat_buf || !obs_seat_out || !reward_out || !done_out)
         return fail(EVG_ERR_INVALID, "rollout_vs_policy: steps >= 1, actions_seat_buf, obs_seat_out, reward_out, done_out required");
     if (seat < 0 || seat > 1 || opponent_policy < 0 || opponent_policy >= EVG_POLICY_COUNT) return fail(EVG_ERR_INVALID, "seat / opponent_policy out of range");
-    EVG_NEED_ALIGNED16(obs_seat_out); EVG_NEED_ALIGNED16(actions_seat_buf); EVG_NEED_ALIGNED16(reward_out); EVG_NEED_ALIGNED16(scores_out);
+    EVG_NEED_ALIGNED16(obs_seat_out); EVG_NEED_ALIGNED16(actions_seat_buf); EVG_NEED_ALIGNED8(reward_out); EVG_NEED_ALIGNED8(scores_out);
     if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_rollout_vs_policy: keyed-Philox handles only");
     EVG_ON_DEVICE(h);
     hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);
@@ -1177,7 +1184,11 @@ const RcclApi* rccl() {
             g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (g_rccl.lib) break;
         }
-        if (!g_rccl.lib) { g_rccl.why = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "?") + ")"; return; }
+        if (!g_rccl.lib) {
+            const char* e = dlerror();                 // ONE call: dlerror() hands the message out once and clears it
+            g_rccl.why = std::string("librccl.so.1 not found (") + (e ? e : "?") + ")";
+            return;
+        }
         auto sym = [](const char* n) { return dlsym(g_rccl.lib, n); };
         g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
         g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));

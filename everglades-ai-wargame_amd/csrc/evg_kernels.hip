@@ -396,17 +396,23 @@ int launch_smart_state(const DevState& S, int player, const void* obs, int seat_
 
 // network output -> orders: one DPP row (16 lanes) per env
 int launch_smart_actions(const DevState& S, int player, const void* obs, int seat_only, const float* q, int32_t* actions, int32_t* directions, int obs_dtype,
-                         void* stream) {
+                         void* stream, const SmartExplore* ex) {
     const dim3 grid((unsigned)(((size_t)S.N * 16 + 255) / 256)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int2* a = reinterpret_cast<int2*>(actions);
     int2* d = reinterpret_cast<int2*>(directions);
+    ExploreArgs X{};
+    if (ex) X = ExploreArgs{S.seed_lo, S.seed_hi, S.env_id_base, S.episode, ex->seat, ex->eps, ex->eps_env, ex->explored};
+#define EVG_LAUNCH_SMART(OT)                                                                                                                     \
+    if (ex) hipLaunchKernelGGL((evg_smart_actions_kernel<OT, true>), grid, block, 0, s, S.N, player, seat_only, (const OT*)obs, q, a, d, X);      \
+    else hipLaunchKernelGGL((evg_smart_actions_kernel<OT, false>), grid, block, 0, s, S.N, player, seat_only, (const OT*)obs, q, a, d, X)
     switch (obs_dtype) {
-        case EVG_OBS_F32: hipLaunchKernelGGL(evg_smart_actions_kernel<float>, grid, block, 0, s, S.N, player, seat_only, (const float*)obs, q, a, d); break;
-        case EVG_OBS_F64: hipLaunchKernelGGL(evg_smart_actions_kernel<double>, grid, block, 0, s, S.N, player, seat_only, (const double*)obs, q, a, d); break;
-        case EVG_OBS_I16: hipLaunchKernelGGL(evg_smart_actions_kernel<int16_t>, grid, block, 0, s, S.N, player, seat_only, (const int16_t*)obs, q, a, d); break;
+        case EVG_OBS_F32: EVG_LAUNCH_SMART(float); break;
+        case EVG_OBS_F64: EVG_LAUNCH_SMART(double); break;
+        case EVG_OBS_I16: EVG_LAUNCH_SMART(int16_t); break;
         default: return -1;
     }
+#undef EVG_LAUNCH_SMART
     return (int)hipGetLastError();
 }
 

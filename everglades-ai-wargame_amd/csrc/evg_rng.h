@@ -9,7 +9,7 @@ namespace evg {
 
 constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
 constexpr uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
-constexpr int RNG_COMBAT = 0, RNG_ACTION = 1, RNG_SWARM = 2, RNG_DELAY = 3;
+constexpr int RNG_COMBAT = 0, RNG_ACTION = 1, RNG_SWARM = 2, RNG_DELAY = 3, RNG_EXPLORE = 4;
 
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll

@@ -12,10 +12,11 @@
  * Conventions
  *   - plain C, no torch types; every pointer marked "device" is a HIP device pointer owned by the
  *     caller (e.g. torch.Tensor.data_ptr()); the handle owns only the persistent game state.
- *   - ALIGNMENT: every device buffer of observations, orders, rewards, scores, features or packed results handed to the library must be
- *     16-byte aligned (the kernels move them with 8- and 16-byte vector accesses: observation rows 16 bytes per lane, order rows as
- *     int2 / uint4, rewards float2, scores int2).  Any hipMalloc / torch allocation is; a slice of one need not be.  Checked by every entry
- *     point: EVG_ERR_INVALID names the pointer.  Byte arrays (done, winner, status, mask, fog planes) have no requirement.
+ *   - ALIGNMENT: every device buffer of observations, orders, features or packed results handed to the library must be 16-byte aligned
+ *     (observation rows move 16 bytes per lane, order rows as int2 / uint4); reward and score buffers 8-byte aligned (one float2 / int2 per
+ *     env, so any env offset into an [N][2] tensor is fine).  Any hipMalloc / torch allocation is 16-byte aligned; a slice of one need not be.
+ *     Checked by every entry point: EVG_ERR_INVALID names the pointer.  Byte arrays (done, winner, status, mask, fog planes) have no
+ *     requirement.
  *   - all calls return 0 on success or a negative evg_status; evg_last_error() gives the text
  *     (thread-local).  No C++ exception crosses the ABI.
  *   - step/reset/random_actions ENQUEUE on the caller's hipStream_t (`stream`, may be NULL for the

@@ -12,6 +12,7 @@ through the C oracle and through the HIP path.
     python oracle/gen_golden.py            # regenerate everything but the 10 000-match sample (about 2 minutes)
     EVG_GOLDEN_ONLY=matches python oracle/gen_golden.py    # tests/golden/matches_10k.npz (about 10 minutes on 6 cores)
     EVG_GOLDEN_ONLY=matches5 python oracle/gen_golden.py   # tests/golden/matches_config5_10k.npz (Cycle_BRush_Turn25 vs SwarmAgent)
+    EVG_GOLDEN_ONLY=custom python oracle/gen_golden.py     # tests/golden/custom_var{A,B,C}.npz (non-default map / unit files; 4 minutes)
 
 Loader recipe: SURVEY.md Appendix B (np.int alias; a stub `gym` package so the real
 gym_everglades/envs/everglades_env.py imports unmodified).
@@ -298,7 +299,32 @@ def pol_zero(ctx, p, obs):
     return np.zeros((7, 2))
 
 
-POLICIES = {"random": (pol_random, pol_random), "wild": (pol_wild, pol_wild), "rush": (pol_rush, pol_rush),
+def _march_hops(obs, target, rows, rot, hop):
+    """_march on another map: `hop` [src][dst] is the next-hop table in the player's own numbering (custom_configs.own_view_hops)."""
+    loc = obs[45::5].astype(int)
+    mov = obs[48::5].astype(int)
+    alive = obs[49::5].astype(int)
+    out = []
+    for k in range(NG):
+        g = (k + rot) % NG
+        if not mov[g] and alive[g] > 0 and loc[g] != target and hop[int(loc[g])][target]:
+            out.append((g, hop[int(loc[g])][target]))
+    out = out[:rows]
+    while len(out) < rows:
+        out.append((0, 0))
+    return np.array(out, dtype=np.float64)
+
+
+def pol_rush_v(ctx, p, obs):
+    return _march_hops(obs, ctx["variant"]["rush_target"][p], 7, int(obs[0]), ctx["variant"]["hops"][p])
+
+
+def pol_brawl_v(ctx, p, obs):
+    return _march_hops(obs, ctx["variant"]["brawl_own"][p], 12, 0, ctx["variant"]["hops"][p])
+
+
+POLICIES = {"random": (pol_random, pol_random), "rush_variant": (pol_rush_v, pol_rush_v), "brawl_variant": (pol_brawl_v, pol_brawl_v),
+            "brawl_variant_v_random": (pol_brawl_v, pol_random), "wild": (pol_wild, pol_wild), "rush": (pol_rush, pol_rush),
             "brawl": (pol_brawl, pol_brawl), "brawl_v_random": (pol_brawl, pol_random),
             "rush_v_random": (pol_rush, pol_random)}
 
@@ -342,7 +368,7 @@ class Runner(object):
         obs = self.env.reset(players={0: None, 1: None}, **self.cfg)
         return obs
 
-    def play(self, policy, seed, env_id, episode=0, full=True, pre_edit=None, script=None, max_turns=400):
+    def play(self, policy, seed, env_id, episode=0, full=True, pre_edit=None, script=None, max_turns=400, variant=None, obs_bound=500):
         """Returns a dict of per-turn arrays.  `script`: optional list of (a0, a1) overriding the policy."""
         tap = FogTap()
         with tap:
@@ -352,7 +378,7 @@ class Runner(object):
                 pre_edit(game)
             obs = self.env._build_observations()
         tr = Tracker(game)
-        ctx = [dict(seed=seed, env_id=env_id, episode=episode, nprng=np.random.default_rng([seed, env_id, p]))
+        ctx = [dict(seed=seed, env_id=env_id, episode=episode, nprng=np.random.default_rng([seed, env_id, p]), variant=variant)
                for p in (0, 1)]
         pols = POLICIES[policy] if policy in POLICIES else (pol_zero, pol_zero)
         rec = dict(obs=[np.stack([obs[0], obs[1]])], actions=[], raw0=[], raw1=[], reward=[], done=[], scores=[],
@@ -396,7 +422,7 @@ class Runner(object):
         out = dict(length=t)
         for k in ("obs", "actions", "reward", "done", "scores", "status", "groups", "nodes", "health", "rank", "fog", "know", "sight"):
             out[k] = np.array(rec[k])
-        assert np.all(out["obs"] == np.round(out["obs"])) and np.abs(out["obs"]).max() <= 500
+        assert np.all(out["obs"] == np.round(out["obs"])) and np.abs(out["obs"]).max() <= obs_bound
         return out
 
 
@@ -676,6 +702,72 @@ def gen_smart_actions_fixture():
     print("smart_actions:", q.shape, actions[0, 0].tolist(), actions[M - 1, 1].tolist(), flush=True)
 
 
+def gen_smart_explore_fixture():
+    """DQNAgent.get_action (agents/Smart_State/DQNAgent.py:130-146) with epsilon > 0 -- the coin `random.random() < self.epsilon`,
+    then get_random_actions (:148-173: np.random.choice(12, 7, replace=False), np.random.choice(5, 7, replace=True), get_swarm_node_number, get_move) or
+    get_best_actions.  Run by the reference's own methods on an object created without __init__, exactly like gen_smart_actions_fixture; the module's
+    `random` and `np` are proxies that serve the three draws from the keyed stream (rng_spec.explore_draws; the agent of row m is env id m, episode
+    m % 3, turn = obs[0]) -- the same technique as load_agent."""
+    sys.path.insert(0, REF)
+    import torch
+    import agents.Smart_State.DQNAgent as D
+    d = np.load(os.path.join(OUT, "smart_actions.npz"))
+    obs, q = d["obs"].astype(np.float64), d["q"]
+    M = obs.shape[0]
+    seed = 20261007
+    eps_levels = np.array([0.0, 0.05, 0.3, 0.5, 0.95, 1.0], np.float32)
+    eps = eps_levels[(np.arange(M)[:, None] + 3 * np.arange(2)[None, :]) % len(eps_levels)]          # [M, 2] float32
+    cur = dict(m=0, p=0)
+
+    class _Std(object):
+        def random(self):
+            L = sys._getframe(1).f_locals
+            return rng_spec.explore_draws(seed, cur["m"], cur["m"] % 3, int(L["obs"][0]), cur["p"])[0] / 4294967296.0
+
+    class _NpRandom(object):
+        def choice(self, a, size, replace=True):
+            L = sys._getframe(1).f_locals
+            coin, swarms, dirs = rng_spec.explore_draws(seed, cur["m"], cur["m"] % 3, int(L["obs"][0]), cur["p"])
+            assert size == 7 and (a, replace) in ((12, False), (5, True))
+            return np.array(swarms if a == 12 else dirs)
+
+    class _Np(object):
+        random = _NpRandom()
+
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+    D.random, D.np = _Std(), _Np()
+    agent = D.DQNAgent.__new__(D.DQNAgent)
+    agent.num_nodes = NN
+    actions, directions = np.zeros((M, 2, 7, 2), np.int32), np.zeros((M, 2, 7, 2), np.int32)
+    explored = np.zeros((M, 2), np.uint8)
+    calls = []
+    orig = D.DQNAgent.get_random_actions
+
+    def tapped(self_, o):
+        calls.append(1)
+        return orig(self_, o)
+
+    D.DQNAgent.get_random_actions = tapped
+    for m in range(M):
+        for p in range(2):
+            cur["m"], cur["p"] = m, p
+            agent.epsilon = float(eps[m, p])
+            agent.policy_net = lambda swarm_obs, m=m, p=p: torch.from_numpy(q[m, p, int(np.argmax(swarm_obs[47:59]))].copy())
+            n0 = len(calls)
+            a, dr = agent.get_action(obs[m, p])
+            explored[m, p] = len(calls) - n0
+            assert a.shape == (7, 2) and np.array_equal(a, a.astype(np.int32)) and np.array_equal(dr, dr.astype(np.int32))
+            actions[m, p], directions[m, p] = a.astype(np.int32), dr.astype(np.int32)
+    D.DQNAgent.get_random_actions = orig
+    D.random, D.np = __import__("random"), np
+    np.savez_compressed(os.path.join(OUT, "smart_explore.npz"), obs=d["obs"], q=q, eps=eps, seed=np.array([seed], np.uint64),
+                        episode=(np.arange(M) % 3).astype(np.uint32), actions=actions, directions=directions, explored=explored)
+    print("smart_explore:", M, "rows x 2 seats, explored", int(explored.sum()), "by epsilon", {float(e): (int(explored[eps == e].sum()), int((eps == e).sum()))
+                                                                                              for e in eps_levels}, flush=True)
+
+
 # ----------------------------------------------------------------------------------------------
 # north-star acceptance sample: 10 000 seeded random-vs-random matches played by the reference
 # ----------------------------------------------------------------------------------------------
@@ -794,6 +886,73 @@ def gen_matches_fixture(procs=6, chunk=50, worker=None, fname="matches_10k.npz")
 
 
 # ----------------------------------------------------------------------------------------------
+# non-default map / unit files: the reference parses them at every reset (everglades_env.py:75-106)
+# ----------------------------------------------------------------------------------------------
+def gen_custom_fixtures(R, only=None):
+    """tests/golden/custom_<variant>.npz: the imported reference playing on the configurations of oracle/custom_configs.py, written to a
+    temporary directory in its own JSON schema and handed to EvergladesEnv.reset(map_file=, unit_file=).  Eight full-state trajectories
+    (random, march-to-a-centre-node, march-to-the-enemy-base, wild) and 200 outcome-only random-vs-random games per variant; the JSON
+    text the reference read is stored in the fixture, so the tests feed the SAME files to tables_from_json."""
+    import json
+    import tempfile
+    import custom_configs as cc
+    demo_map = json.load(open(os.path.join(REF, "config", "DemoMap.json")))
+    demo_units = json.load(open(os.path.join(REF, "config", "UnitDefinitions.json")))
+    saved_cfg = dict(R.cfg)
+    tmp = tempfile.mkdtemp(prefix="evg_custom_")
+    for name in cc.VARIANTS:
+        if only and only != name:
+            continue
+        t0 = time.time()
+        V = cc.VARIANTS[name]
+        mobj, uobj, p1map = cc.variant_objects(name, demo_map, demo_units)
+        mtxt, utxt = cc.json_text(mobj), cc.json_text(uobj)
+        mpath, upath = os.path.join(tmp, name + "_map.json"), os.path.join(tmp, name + "_units.json")
+        open(mpath, "w").write(mtxt), open(upath, "w").write(utxt)
+        R.cfg = dict(saved_cfg, map_file=mpath, unit_file=upath)
+        pre_edit = None
+        if V["p1_node_map"] is not None:
+            def pre_edit(game, _m=list(p1map)):
+                game.p1_node_map = _m            # read at call time by _vec_convert_node (server.py:91-94)
+        adj = cc.adjacency(mobj)
+        ident = list(range(12))
+        inv = [p1map.index(i) if i in p1map else 0 for i in range(12)]
+        variant = dict(hops={0: cc.own_view_hops(adj, ident, ident), 1: cc.own_view_hops(adj, p1map, p1map)}, rush_target=V["rush_target"],
+                       brawl_own={0: V["brawl_node"], 1: p1map[V["brawl_node"]]})
+        del inv
+        bound = max(int(n["ControlPoints"]) for n in mobj["nodes"])
+        games, metas = [], []
+        plan = ["random", "random", "brawl_variant", "brawl_variant", "rush_variant", "rush_variant", "brawl_variant_v_random", "wild"]
+        for i, pol in enumerate(plan):
+            seed, env_id, episode = 9000 + 31 * i + len(name), 5 * i + 2, i % 3
+            g = R.play(pol, seed, env_id, episode, pre_edit=pre_edit, variant=variant, obs_bound=bound)
+            games.append(g)
+            metas.append(dict(policy=pol, seed=seed, env_id=env_id, episode=episode))
+        d = pack(games, metas)
+        B, seedB = 200, 20261006
+        res = dict(seed=np.uint64(seedB), length=np.zeros(B, np.int32), scores=np.zeros((B, 2), np.int32), status=np.zeros(B, np.uint8),
+                   reward=np.zeros((B, 2)), obs_sum=np.zeros((B, 151, 2), np.int32), health_final=np.zeros((B, 2, NU)))
+        for i in range(B):
+            g = R.play("random", seedB, i, 0, pre_edit=pre_edit, variant=variant, obs_bound=bound)
+            T = g["length"]
+            res["length"][i], res["scores"][i], res["status"][i], res["reward"][i] = T, g["scores"][T - 1], g["status"][T - 1], g["reward"][T - 1]
+            res["obs_sum"][i, :T + 1] = g["obs"].astype(np.int64).sum(axis=2)
+            res["health_final"][i] = g["health"][T]
+        for k, v in res.items():
+            d["bulk_" + k] = v
+        # the text of the files the reference read; "" = the reference's own DemoMap.json / UnitDefinitions.json (not copied into the fixture)
+        d["map_json"], d["unit_json"] = np.array(mtxt if V["map"] is not None else ""), np.array(utxt if V["units"] is not None else "")
+        d["p1_node_map"] = np.array(p1map, np.int32)
+        d["p1_node_map_edited"] = np.array(int(V["p1_node_map"] is not None), np.int32)
+        np.savez_compressed(os.path.join(OUT, "custom_%s.npz" % name), **d)
+        w = res["scores"]
+        print("custom", name, "lengths", d["length"].tolist(), "status", [int(s[l - 1]) for s, l in zip(d["status"], d["length"])],
+              "bulk status histogram", np.bincount(res["status"], minlength=4).tolist(), "wins p0/p1/tie",
+              [int((w[:, 0] > w[:, 1]).sum()), int((w[:, 1] > w[:, 0]).sum()), int((w[:, 0] == w[:, 1]).sum())], "%.0fs" % (time.time() - t0), flush=True)
+    R.cfg = saved_cfg
+
+
+# ----------------------------------------------------------------------------------------------
 def kat_script():
     """deterministic no-combat trajectory."""
     z = np.zeros((7, 2))
@@ -845,9 +1004,16 @@ def main():
     if os.environ.get("EVG_GOLDEN_ONLY") == "config1":
         gen_config1_fixture(R)
         return
+    if (os.environ.get("EVG_GOLDEN_ONLY") or "").startswith("custom"):      # custom | custom:varA
+        gen_custom_fixtures(R, only=(os.environ["EVG_GOLDEN_ONLY"].split(":") + [None])[1])
+        return
     if os.environ.get("EVG_GOLDEN_ONLY") == "smart":
         gen_smart_state_fixture()
         gen_smart_actions_fixture()
+        gen_smart_explore_fixture()
+        return
+    if os.environ.get("EVG_GOLDEN_ONLY") == "explore":
+        gen_smart_explore_fixture()
         return
     only = os.environ.get("EVG_GOLDEN_ONLY")
 
@@ -884,8 +1050,10 @@ def main():
 
     gen_smart_state_fixture()
     gen_smart_actions_fixture()
+    gen_smart_explore_fixture()
     gen_stock_mt_fixture(R)
     gen_config1_fixture(R)
+    gen_custom_fixtures(R)
 
     # 4. bulk random-vs-random: outcomes + per-turn checksums only
     B = 120

@@ -9,6 +9,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "_build", "libevg_oracle.so")
+SANITIZED_LIB = os.environ.get("EVG_ORACLE_LIB")      # `make -C oracle sanitize`: the ASan + UBSan build of the same source (test infrastructure reads
+                                                       # the environment; the product never does)
 
 NP, NG, NN, NU, NA, OBS = 2, 12, 11, 100, 7, 105
 
@@ -57,6 +59,44 @@ def demo_tables():
     return t
 
 
+def tables_from_json_text(map_text=None, unit_text=None, p1_node_map=None):
+    """The oracle's OWN parser of the reference's two configuration files (independent of the product's tables_from_json):
+    board_init (server.py:40-100: per-node ControlPoints / StructureDefense / Resource / TeamStart, directed Connections),
+    unitTypes_init (server.py:103-131: unit id = position in the file, names compared in lower case) and the army of
+    everglades_env.py:145-156 (group g is unit class ['controller', 'striker', 'tank'][g % 3]).  None keeps the DemoMap table."""
+    import json
+    t = demo_tables()
+    if map_text is not None:
+        nodes = json.loads(map_text)["nodes"]
+        assert [n["ID"] for n in nodes] == list(range(1, 12))
+        for a in range(12):
+            for b in range(12):
+                t.node_dist[a][b] = 0
+        for n in nodes:
+            i = n["ID"]
+            t.node_control_points[i], t.node_defense[i], t.node_team_start[i] = n["ControlPoints"], float(n["StructureDefense"]), n["TeamStart"]
+            t.node_resource[i] = (1 if "DEFENSE" in n["Resource"] else 0) | (2 if "OBSERVE" in n["Resource"] else 0)   # server.py:442-443
+            assert "DEFEND" not in n["Resource"]                    # server.py:595: would switch the fort bonus on; not modelled
+            for c in n["Connections"]:
+                if t.node_dist[i][c["ConnectedID"]] == 0:            # the first listed connection wins (server.py:245-249)
+                    t.node_dist[i][c["ConnectedID"]] = c["Distance"]
+    if unit_text is not None:
+        units = json.loads(unit_text)["units"]
+        ids = {}
+        t.num_unit_types = len(units)
+        for uid, u in enumerate(units):
+            ids[u["Name"].lower()] = uid
+            t.unit_health[uid], t.unit_damage[uid], t.unit_speed[uid] = u["Health"], u["Damage"], u["Speed"]
+            t.unit_control[uid], t.unit_cost[uid] = u["Control"], u["Cost"]
+        for p in range(2):
+            for g in range(12):
+                t.group_type[p][g] = ids[["controller", "striker", "tank"][g % 3]]
+    if p1_node_map is not None:
+        for i, v in enumerate(p1_node_map):
+            t.p1_node_map[i] = int(v)
+    return t
+
+
 def build(force=False):
     src = os.path.join(HERE, "evg_oracle.c")
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
@@ -72,7 +112,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB):
             build()
-        L = C.CDLL(LIB)
+        L = C.CDLL(SANITIZED_LIB or LIB)
         L.evo_create.restype = C.c_void_p
         L.evo_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(Tables), C.c_int]
         L.evo_destroy.argtypes = [C.c_void_p]
@@ -87,6 +127,8 @@ def lib():
         L.evo_mt_randint_stream.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.evo_smart_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.evo_smart_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.evo_smart_get_action.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
         L.evo_get_move.restype = C.c_int
         L.evo_get_move.argtypes = [C.c_int, C.c_int]
         L.evo_fog_of_war.argtypes = [C.c_void_p, C.c_void_p]
@@ -246,6 +288,19 @@ def smart_actions(q, obs_rows):
     d = np.zeros((o.shape[0], 7, 2), np.int32)
     lib().evo_smart_actions(_p(qq), _p(o), o.shape[0], _p(a), _p(d))
     return a, d
+
+
+def smart_get_action(q, obs_rows, seed, env_ids, episodes, player, eps):
+    """DQNAgent.get_action (epsilon coin, then get_random_actions or get_best_actions) for m agents: q [m, 12, 5] float32, obs_rows [m, 105], env_ids /
+    episodes [m] (the keys of the agents' draws, rng_spec.explore_draws), eps [m] float32 -> (actions [m, 7, 2], directions [m, 7, 2], explored [m])."""
+    qq = np.ascontiguousarray(q, np.float32)
+    o = np.ascontiguousarray(obs_rows, np.float64)
+    m = o.shape[0]
+    ids, eps_, epi = np.ascontiguousarray(env_ids, np.uint32), np.ascontiguousarray(eps, np.float32), np.ascontiguousarray(episodes, np.uint32)
+    assert qq.shape == (m, NG, 5) and ids.shape == (m,) and epi.shape == (m,) and eps_.shape == (m,)
+    a, d, x = np.zeros((m, 7, 2), np.int32), np.zeros((m, 7, 2), np.int32), np.zeros(m, np.uint8)
+    lib().evo_smart_get_action(_p(qq), _p(o), m, int(seed), _p(ids), _p(epi), int(player), _p(eps_), _p(a), _p(d), _p(x))
+    return a, d, x
 
 
 def get_move(node0, direction):

@@ -32,13 +32,18 @@ Generator: Philox4x32-10 (Salmon et al., SC'11), 64-bit key, 128-bit counter.
   swarm   (domain 2): shuffle of the SwarmAgent attack list (swarm_agent.py:86-87), see agents.
   delay   (domain 3): the `random.random() > 0.68` coin of random_actions_delay.py: word 0 of block 0 as a
                       fraction of 2^32.
+  explore (domain 4): DQNAgent.get_action of the Smart_State agent (agents/Smart_State/DQNAgent.py:130-173), one agent call =
+                      (env, episode, turn = obs[0], player): halves 0..6 of block 0 pick the 7 distinct swarms of
+                      np.random.choice(12, 7, replace=False) (partial Fisher-Yates as in `random_action_rows`), halves 0..6 of
+                      block 1 the 7 directions of np.random.choice(5, 7, replace=True) as (half * 5) >> 16, and the two spare
+                      halves make the epsilon coin: random.random() = (half 7 of block 0 << 16 | half 7 of block 1) / 2^32.
 """
 
 M0, M1 = 0xD2511F53, 0xCD9E8D57
 W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK = 0xFFFFFFFF
 
-DOMAIN_COMBAT, DOMAIN_ACTION, DOMAIN_SWARM, DOMAIN_DELAY = 0, 1, 2, 3
+DOMAIN_COMBAT, DOMAIN_ACTION, DOMAIN_SWARM, DOMAIN_DELAY, DOMAIN_EXPLORE = 0, 1, 2, 3, 4
 
 
 def philox4x32_10(ctr, key):
@@ -108,6 +113,17 @@ def delay_uniform(seed, env_id, episode, turn, player):
     """Stand-in for random.random() in random_actions_delay.get_action: a float in [0, 1)."""
     w = philox4x32_10(_ctr(DOMAIN_DELAY, 0, turn, 0, player, episode, env_id), _key(seed))
     return w[0] / 4294967296.0
+
+
+def explore_draws(seed, env_id, episode, turn, player):
+    """One DQNAgent.get_action call: (coin as a 32-bit integer -- random.random() = coin / 2^32 --, the 7 swarms, the 7 directions)."""
+    h0 = halves(philox4x32_10(_ctr(DOMAIN_EXPLORE, 0, turn, 0, player, episode, env_id), _key(seed)))
+    h1 = halves(philox4x32_10(_ctr(DOMAIN_EXPLORE, 1, turn, 0, player, episode, env_id), _key(seed)))
+    g = list(range(12))
+    for i in range(7):
+        j = i + ((h0[i] * (12 - i)) >> 16)
+        g[i], g[j] = g[j], g[i]
+    return (h0[7] << 16) | h1[7], g[:7], [(h1[i] * 5) >> 16 for i in range(7)]
 
 
 if __name__ == "__main__":

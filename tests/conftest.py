@@ -34,6 +34,10 @@ TRAJ_FILES = ["traj_random.npz", "traj_wild.npz", "traj_rush.npz", "traj_brawl.n
               "traj_rush_v_random.npz", "kat_nocombat.npz"]
 
 
+# the imported reference on NON-default map / unit files (oracle/custom_configs.py; EvergladesEnv.reset(map_file=, unit_file=))
+CUSTOM_FILES = ["custom_varA.npz", "custom_varB.npz", "custom_varC.npz"]
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle as om

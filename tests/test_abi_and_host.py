@@ -354,3 +354,119 @@ def test_bench_stdout_line_is_compact_and_complete():
     # step launches / (step launches + collective path), one run
     assert 0.9 < exp["weak_scaling_efficiency_if_wire_free"] < 1.0 and exp["collective_us_1rank"] > 0
     assert bench.expected_if_wire_free(8, 12345) is None
+
+
+def test_a_missing_rccl_is_reported_as_evg_err_comm(tmp_path):
+    """include/evg.h promises EVG_ERR_COMM from evg_comm_unique_id / evg_comm_init / evg_gather_returns on a host without RCCL.  Every box here has RCCL, so
+    the dlopen is made to fail: a preloaded shim turns every dlopen of a name containing "rccl" into a dlopen of a file that does not exist (which fails
+    AND sets dlerror(), the case the library's message is built from -- dlerror() hands its text out once).  Fresh process, no torch: nothing has loaded
+    librccl before."""
+    import subprocess
+    import sys
+    shim_src = tmp_path / "no_rccl.c"
+    shim_src.write_text('#define _GNU_SOURCE\n#include <dlfcn.h>\n#include <string.h>\n'
+                        'void* dlopen(const char* name, int flags) {\n'
+                        '    static void* (*real)(const char*, int);\n'
+                        '    if (!real) real = (void* (*)(const char*, int))dlsym(RTLD_NEXT, "dlopen");\n'
+                        '    if (name && strstr(name, "rccl")) return real("/nonexistent/evg-test/librccl.so.1", flags);\n'
+                        '    return real(name, flags);\n}\n')
+    shim = tmp_path / "no_rccl.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", str(shim_src), "-o", str(shim), "-ldl"])
+    lib_path = os.path.join(ROOT, "everglades-ai-wargame_amd", "libevg.so")
+    code = ("import ctypes as C\n"
+            "lib = C.CDLL(%r)\n"
+            "lib.evg_last_error.restype = C.c_char_p\n"
+            "buf = C.create_string_buffer(128)\n"
+            "rc = lib.evg_comm_unique_id(buf)\n"
+            "print(rc, lib.evg_last_error().decode())\n" % lib_path)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LD_PRELOAD=str(shim)), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, msg = out.stdout.strip().split(" ", 1)
+    assert int(rc) == -6 and "RCCL is not available" in msg and "librccl.so.1 not found (" in msg and "/nonexistent/evg-test" in msg, out.stdout
+
+
+def test_gym_registration_runs_with_a_gym_package():
+    """INTEGRATION.md section 1 offers `gym.make('everglades-v0')` (the reference: gym_everglades/__init__.py:3-6).  gym is in neither image, so the
+    registration line is executed here against a stand-in `gym` whose register() records its arguments and whose make() resolves the
+    'module:Class' entry point the way gym does: the id is registered once, the entry point imports, and the object has the reference's interface.
+    A failure inside register() must propagate (only a missing gym is tolerated)."""
+    import subprocess
+    import sys
+    code = '''
+import importlib, sys, types
+calls = []
+gym = types.ModuleType("gym"); envs = types.ModuleType("gym.envs"); reg = types.ModuleType("gym.envs.registration")
+def register(**kw): calls.append(kw)
+def make(id):
+    spec = [c for c in calls if c["id"] == id][0]["entry_point"]
+    mod, cls = spec.split(":")
+    return getattr(importlib.import_module(mod), cls)()
+reg.register = register; envs.registration = reg; gym.envs = envs; gym.make = make
+sys.modules.update({"gym": gym, "gym.envs": envs, "gym.envs.registration": reg})
+sys.path.insert(0, %r)
+import everglades_amd
+assert everglades_amd.GYM_REGISTERED is True
+assert calls == [dict(id="everglades-v0", entry_point="everglades_amd:EvergladesEnv")], calls
+env = gym.make("everglades-v0")
+assert type(env) is everglades_amd.EvergladesEnv and env.num_actions_per_turn == 7 and env.observation_space.shape == (105,)
+for name in ("reset", "step", "render", "close"):
+    assert callable(getattr(env, name))
+# a registration that fails is an error, not a silent skip
+def broken(**kw): raise RuntimeError("id already registered")
+reg.register = broken
+for m in [m for m in sys.modules if m == "everglades_amd" or m.startswith("everglades_amd.")]:
+    del sys.modules[m]
+try:
+    import everglades_amd
+except RuntimeError as e:
+    assert "already registered" in str(e)
+else:
+    raise AssertionError("a failing register() was swallowed")
+print("ok")
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+    import everglades_amd
+    assert everglades_amd.GYM_REGISTERED is False          # this image has no gym: nothing was registered, nothing failed
+
+
+def test_tables_from_json_refuses_what_the_reference_would_play_differently(evg, tmp_path):
+    """tables_from_json's domain is what tests/golden/custom_*.npz pin against the reference.  Files the reference would play DIFFERENTLY from
+    the integer tables are refused instead of being approximated: nodes out of ID order (the reference's fog mask mixes list positions with IDs,
+    server.py:409-418), a 'DEFEND' resource (switches the fortress bonus on, server.py:595), fractional unit stats / distances / control points
+    (the reference would compute with the float), a map without exactly one start node per player."""
+    import copy
+    import custom_configs as cc
+
+    def write(name, obj):
+        path = tmp_path / name
+        path.write_text(json.dumps(obj))
+        return str(path)
+
+    good_map, good_units = write("m.json", cc.MAP_A), write("u.json", cc.UNITS_A)
+    t = evg.tables_from_json(good_map, good_units)
+    assert t.node_dist[2][3] == 3 and t.node_dist[3][2] == 4 and t.node_dist[6][5] == 2 and t.node_dist[5][6] == 0      # directed, one-way
+    assert t.node_resource[5] == 3 and t.node_resource[9] == 0 and t.node_defense[2] == 2.1 and t.node_control_points[6] == 511
+    assert [t.group_type[0][g] for g in range(3)] == [2, 0, 1] and t.unit_speed[0] == 3                                 # ids follow the file order
+
+    def bad_map(edit):
+        m = copy.deepcopy(cc.MAP_A)
+        edit(m)
+        with pytest.raises(ValueError):
+            evg.tables_from_json(write("bad.json", m), good_units)
+
+    bad_map(lambda m: m["nodes"].reverse())
+    bad_map(lambda m: m["nodes"][3]["Resource"].append("DEFEND"))
+    bad_map(lambda m: m["nodes"][0]["Connections"][0].update(Distance=2.5))
+    bad_map(lambda m: m["nodes"][4].update(ControlPoints=100.5))
+    bad_map(lambda m: m["nodes"][4].update(TeamStart=0))
+    bad_map(lambda m: m["nodes"][0].update(TeamStart=-1))
+    bad_map(lambda m: m["nodes"][0]["Connections"][0].update(ConnectedID=12))
+    u = copy.deepcopy(cc.UNITS_A)
+    u["units"][1]["Health"] = 2.5
+    with pytest.raises(ValueError):
+        evg.tables_from_json(good_map, write("bad_u.json", u))
+    u = copy.deepcopy(cc.UNITS_B)
+    u["units"].append(dict(u["units"][0], Name="Fifth"))
+    with pytest.raises(ValueError):
+        evg.tables_from_json(good_map, write("bad_u5.json", u))

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden, golden_initial_state, TRAJ_FILES
+from conftest import load_golden, golden_initial_state, TRAJ_FILES, CUSTOM_FILES
 
 pytestmark = pytest.mark.gpu
 REWARD_ATOL = 1e-6
@@ -32,13 +32,13 @@ def check_state(env, ora_state, what=""):
         assert np.array_equal(s[k], ora_state[k]), (what, k)
 
 
-@pytest.mark.parametrize("fname", TRAJ_FILES + ["edit_annihilation.npz"])
-def test_golden_through_abi(evg, fname):
+def _replay_fixture_through_abi(evg, d, fname, **env_kw):
+    """Every game of a full-state trajectory fixture through the C-ABI, compared turn by turn (observations, scores, status, rewards, float64
+    health bits, packed groups and nodes, fog / knowledge / sightings)."""
     from gen_policies import sighting_rows
-    d = load_golden(fname)
     for g in range(len(d["length"])):
         T = int(d["length"][g])
-        env = evg.EvergladesVecEnv(1, seed=int(d["seed"][g]), env_id_base=int(d["env_id"][g]), obs_dtype="float64", auto_reset=False)
+        env = evg.EvergladesVecEnv(1, seed=int(d["seed"][g]), env_id_base=int(d["env_id"][g]), obs_dtype="float64", auto_reset=False, **env_kw)
         env.reset()
         env.set_state(*golden_initial_state(d, g))
         assert np.array_equal(_np(env.observe())[0], d["obs"][g, 0].astype(np.float64)), ("initial obs", g)
@@ -59,6 +59,83 @@ def test_golden_through_abi(evg, fname):
                 assert np.array_equal(sighting_rows(sg[p], d["rank"][g, t + 1, 1 - p], d["obs"][g, t + 1, 1 - p, 46:105:5]),
                                       d["sight"][g, t + 1, p]), ("sightings", fname, g, t, p)
         env.close()
+
+
+@pytest.mark.parametrize("fname", TRAJ_FILES + ["edit_annihilation.npz"])
+def test_golden_through_abi(evg, fname):
+    _replay_fixture_through_abi(evg, load_golden(fname), fname)
+
+
+def _custom_fixture_files(d, fname, tmp_path):
+    """The JSON text the reference read when it played a custom_*.npz fixture, written out again as files -> reset()/tables_from_json kwargs."""
+    kw = {}
+    for key, arg in (("map_json", "map_file"), ("unit_json", "unit_file")):
+        if str(d[key]):
+            path = tmp_path / (fname + "_" + arg + ".json")
+            path.write_text(str(d[key]))
+            kw[arg] = str(path)
+    return kw
+
+
+@pytest.mark.parametrize("force_ieee_div", [False, True])
+@pytest.mark.parametrize("fname", CUSTOM_FILES)
+def test_non_default_map_and_unit_files_through_abi(evg, fname, force_ieee_div, tmp_path):
+    """The runtime-table path pinned by the REFERENCE (not only by the oracle): tests/golden/custom_*.npz were played by the imported
+    reference on non-default map / unit files (oracle/custom_configs.py) handed to EvergladesEnv.reset(map_file=, unit_file=)
+    (everglades_env.py:75-106 -> server.py:24-131).  Here the same files go through tables_from_json -> evg_create: eight full-state
+    trajectories and 200 outcome-only games per variant, once with the quotient evg_create chooses for the table set (tabulated
+    reciprocal where validated, else true division) and once with the true-division branch forced (diagnostic library)."""
+    d = load_golden(fname)
+    files = _custom_fixture_files(d, fname, tmp_path)
+    tables = evg.tables_from_json(p1_node_map=d["p1_node_map"].tolist(), **files)
+    extra = dict(library=evg._lib.DIAG_LIB_PATH, diag=dict(force_ieee_div=True)) if force_ieee_div else {}
+    _replay_fixture_through_abi(evg, d, fname, tables=tables, **extra)
+    B = len(d["bulk_length"])
+    for form in ("stepwise", "persistent"):
+        env = evg.EvergladesVecEnv(B, seed=int(d["bulk_seed"]), obs_dtype="float64", auto_reset=False, tables=tables, **extra)
+        obs = env.reset()
+        assert np.array_equal(_np(obs).sum(axis=2).astype(np.int32), d["bulk_obs_sum"][:, 0])
+        if form == "persistent":           # no auto-reset: a finished env is frozen, so the final state of every game is still there after 150 turns
+            env.rollout_random(150, turns_per_launch=150)
+            assert np.array_equal(env.get_state()["health"], d["bulk_health_final"])
+            st = env.episode_stats()
+            assert np.array_equal(st["length"], d["bulk_length"])
+            w = d["bulk_scores"]
+            assert st["totals"].tolist() == [B, int((w[:, 0] > w[:, 1]).sum()), int((w[:, 1] > w[:, 0]).sum()), int((w[:, 0] == w[:, 1]).sum())]
+            env.close()
+            continue
+        fs, fst, fr = np.zeros((B, 2), np.int32), np.zeros(B, np.uint8), np.zeros((B, 2))
+        for t in range(150):
+            obs, rew, done, info = env.step(env.random_actions())
+            live = d["bulk_length"] > t
+            assert np.array_equal(_np(obs).sum(axis=2).astype(np.int32)[live], d["bulk_obs_sum"][live, t + 1]), (fname, t)
+            e = d["bulk_length"] == t + 1
+            fs[e], fst[e], fr[e] = _np(info["scores"])[e], _np(info["status"])[e], _np(rew)[e]
+        assert np.array_equal(fs, d["bulk_scores"]) and np.array_equal(fst, d["bulk_status"])
+        assert np.allclose(fr, d["bulk_reward"], rtol=0, atol=REWARD_ATOL)
+        assert np.array_equal(env.get_state()["health"], d["bulk_health_final"])
+        env.close()
+
+
+def test_dropin_reset_with_map_and_unit_files_replays_the_reference(evg, tmp_path):
+    """The replaced interface itself: EvergladesEnv.reset(players=, config_dir=, map_file=, unit_file=, ...) of the single-game drop-in on
+    the non-default files of custom_varA / custom_varB, dict actions in, dict observations / rewards out -- the games of the fixture that
+    start at episode 0, against what the reference returned from the same calls."""
+    for fname in ("custom_varA.npz", "custom_varB.npz"):
+        d = load_golden(fname)
+        files = _custom_fixture_files(d, fname, tmp_path)
+        for g in range(len(d["length"])):
+            if int(d["episode"][g]) != 0:
+                continue
+            env = evg.EvergladesEnv(seed=int(d["seed"][g]), env_id=int(d["env_id"][g]))
+            obs = env.reset(players={0: None, 1: None}, config_dir=str(tmp_path) + "/", output_dir="/tmp/unused/", pnames={0: "a", 1: "b"}, debug=False, **files)
+            assert np.array_equal(np.stack([obs[0], obs[1]]), d["obs"][g, 0].astype(np.float64))
+            for t in range(int(d["length"][g])):
+                a = d["actions"][g, t].astype(np.float64)
+                obs, reward, done, _ = env.step({0: a[0], 1: a[1]})
+                assert np.array_equal(np.stack([obs[0], obs[1]]), d["obs"][g, t + 1].astype(np.float64)), (fname, g, t)
+                assert done == d["done"][g, t] and abs(reward[0] - d["reward"][g, t, 0]) < 1e-12 and abs(reward[1] - d["reward"][g, t, 1]) < 1e-12
+            env.close()
 
 
 def test_bulk_random_matches_reference(evg):
@@ -1271,14 +1348,18 @@ def test_abi_error_paths_on_a_device(evg):
         big_obs = torch.zeros((9, 2, 105), device="cuda")
         big_act = torch.zeros((9, 2, 7, 2), dtype=torch.int32, device="cuda")
 
-        def refused(rc, name):
-            assert rc == -1 and b"16-byte aligned" in lib.evg_last_error() and name in lib.evg_last_error(), (rc, lib.evg_last_error())
+        def refused(rc, name, need=b"16-byte aligned"):
+            assert rc == -1 and need in lib.evg_last_error() and name in lib.evg_last_error(), (rc, lib.evg_last_error())
         refused(lib.evg_reset(h, None, off(big_obs), None), b"obs_out")
         refused(lib.evg_observe(h, off(big_obs), None), b"obs_out")
         refused(lib.evg_step(h, p(act), off(big_obs), p(rew), p(done), None, None, None, None), b"obs_out")
         refused(lib.evg_step(h, off(big_act, 8), p(obs), p(rew), p(done), None, None, None, None), b"actions")
-        refused(lib.evg_step(h, p(act), p(obs), off(big_obs, 8), p(done), None, None, None, None), b"reward_out")
-        refused(lib.evg_step(h, p(act), p(obs), p(rew), p(done), None, off(sc, 8), None, None), b"scores_out")
+        # rewards and scores are one float2 / int2 per env: 8 bytes suffice (an odd env offset into an [N][2] tensor is a legal buffer), 4 do not
+        refused(lib.evg_step(h, p(act), p(obs), off(big_obs, 4), p(done), None, None, None, None), b"reward_out", b"8-byte aligned")
+        refused(lib.evg_step(h, p(act), p(obs), p(rew), p(done), None, off(sc, 4), None, None), b"scores_out", b"8-byte aligned")
+        big_sc = torch.zeros((9, 2), dtype=torch.int32, device="cuda")
+        assert lib.evg_step(h, p(act), p(obs), off(big_obs, 8), p(done), None, off(big_sc, 8), None, None) == 0, lib.evg_last_error()
+        torch.cuda.synchronize()
         refused(lib.evg_random_actions(h, off(big_act, 8), None), b"actions_out")
         refused(lib.evg_scripted_actions(h, 1, 0, p(obs), off(big_act, 8), None), b"actions_out")
         refused(lib.evg_rollout_random(h, 3, 1, p(act), off(big_obs), p(rew), p(done), None, None, None, None, None), b"obs_out")

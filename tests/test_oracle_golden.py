@@ -4,7 +4,7 @@ rewards within 1e-12 (same float64 arithmetic)."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, golden_initial_state, TRAJ_FILES
+from conftest import load_golden, golden_initial_state, TRAJ_FILES, CUSTOM_FILES
 
 
 def check_sightings(records, d, g, t):
@@ -17,10 +17,10 @@ def check_sightings(records, d, g, t):
         assert np.array_equal(got, want), ("opposing-group sightings", g, t, p, got.tolist(), want.tolist())
 
 
-def replay(om, d, g, check_state=True):
+def replay(om, d, g, check_state=True, tables=None):
     seed, env_id, episode = int(d["seed"][g]), int(d["env_id"][g]), int(d["episode"][g])
     T = int(d["length"][g])
-    o = om.Oracle(1, seed=seed, env_id_base=env_id)
+    o = om.Oracle(1, seed=seed, env_id_base=env_id, tables=tables)
     obs = o.reset()
     if episode or not np.array_equal(d["health"][g, 0], o.get_state()["health"][0]):
         # fixture starts from another episode index or from an edited position
@@ -54,6 +54,56 @@ def test_trajectories_bit_exact(oracle_mod, fname):
     d = load_golden(fname)
     for g in range(len(d["length"])):
         replay(oracle_mod, d, g)
+
+
+def custom_oracle_tables(om, d):
+    """Oracle tables of a custom_*.npz fixture from the JSON text the reference itself read ("" = its own DemoMap / UnitDefinitions)."""
+    return om.tables_from_json_text(str(d["map_json"]) or None, str(d["unit_json"]) or None, d["p1_node_map"].tolist())
+
+
+@pytest.mark.parametrize("fname", CUSTOM_FILES)
+def test_non_default_map_and_unit_files_bit_exact(oracle_mod, fname):
+    """EvergladesEnv.reset(map_file=, unit_file=) (everglades_env.py:75-106 -> server.py:24-131) on NON-default files: the imported
+    reference played on the configurations of oracle/custom_configs.py (directed / odd distances, a one-way edge, control points up to
+    511, non-dyadic defenses, moved resources and bases, reordered unit file with every stat changed, four unit types; varC: a board
+    flip that is not its own inverse).  Eight full-state trajectories and 200 outcome-only games per variant."""
+    d = load_golden(fname)
+    t = custom_oracle_tables(oracle_mod, d)
+    ends = set()
+    for g in range(len(d["length"])):
+        replay(oracle_mod, d, g, tables=t)
+        ends.add(int(d["status"][g, d["length"][g] - 1]))
+    assert 1 in ends and (2 in ends or fname == "custom_varC.npz")          # both TimeExpired and BaseCapture endings are in the fixture
+    B = len(d["bulk_length"])
+    o = oracle_mod.Oracle(B, seed=int(d["bulk_seed"]), env_id_base=0, tables=t)
+    obs = o.reset()
+    assert np.array_equal(obs.sum(axis=2).astype(np.int32), d["bulk_obs_sum"][:, 0])
+    fs, fst, fr, fh = np.zeros((B, 2), np.int32), np.zeros(B, np.uint8), np.zeros((B, 2)), np.zeros((B, 2, 100))
+    for tt in range(150):
+        obs, reward, done, info = o.step(o.random_actions())
+        live = d["bulk_length"] > tt
+        assert np.array_equal(obs.sum(axis=2).astype(np.int32)[live], d["bulk_obs_sum"][live, tt + 1]), tt
+        e = d["bulk_length"] == tt + 1
+        fs[e], fst[e], fr[e], fh[e] = info["scores"][e], info["status"][e], reward[e], o.get_state()["health"][e]
+    assert np.array_equal(fs, d["bulk_scores"]) and np.array_equal(fst, d["bulk_status"]) and np.array_equal(fh, d["bulk_health_final"])
+    assert np.allclose(fr, d["bulk_reward"], rtol=0, atol=1e-12)
+
+
+def test_product_and_oracle_parse_the_same_tables(oracle_mod, tmp_path):
+    """The product's tables_from_json (host code, no device needed) and the oracle's own parser agree byte for byte on every variant."""
+    import ctypes as C
+    import everglades_amd
+    for fname in CUSTOM_FILES:
+        d = load_golden(fname)
+        kw = {}
+        for key, arg in (("map_json", "map_file"), ("unit_json", "unit_file")):
+            if str(d[key]):
+                path = tmp_path / (fname + "_" + arg + ".json")
+                path.write_text(str(d[key]))
+                kw[arg] = str(path)
+        t = everglades_amd.tables_from_json(p1_node_map=d["p1_node_map"].tolist(), **kw)
+        ot = custom_oracle_tables(oracle_mod, d)
+        assert C.sizeof(t) == C.sizeof(ot) and bytes(t) == bytes(ot), fname
 
 
 def test_kat_values_from_survey(oracle_mod):
@@ -315,3 +365,31 @@ def test_smart_state_and_smart_actions_oracle_vs_reference_fixtures(oracle_mod):
             for i in range(7):
                 sw, node = a["actions"][m, p, i]
                 assert node == oracle_mod.get_move(int(a["obs"][m, p, 45 + 5 * sw]) - 1, int(a["directions"][m, p, i, 1]))
+
+
+def test_smart_get_action_with_epsilon_oracle_vs_reference_fixture(oracle_mod):
+    """DQNAgent.get_action (agents/Smart_State/DQNAgent.py:130-173) with epsilon > 0: tests/golden/smart_explore.npz was produced by the reference's own
+    get_action / get_random_actions / get_best_actions with its three draws served from the keyed stream (rng_spec.explore_draws).  The oracle's
+    restatement reproduces which agents explored and every order / direction row; the spec in Python agrees with the oracle's C on the draws."""
+    import rng_spec
+    d = load_golden("smart_explore.npz")
+    M = d["obs"].shape[0]
+    ids = np.arange(M, dtype=np.uint32)
+    for p in range(2):
+        a, dr, x = oracle_mod.smart_get_action(d["q"][:, p], d["obs"][:, p].astype(np.float64), int(d["seed"][0]), ids, d["episode"], p, d["eps"][:, p])
+        assert np.array_equal(x, d["explored"][:, p]) and np.array_equal(a, d["actions"][:, p]) and np.array_equal(dr, d["directions"][:, p]), p
+    ex = d["explored"].astype(bool)
+    assert ex.any() and (~ex).any() and not ex[d["eps"] == 0].any() and ex[d["eps"] == 1].all()
+    # explored rows: 7 distinct swarms, directions in 0..4 with repeats somewhere, node = get_move(location - 1, direction)
+    rows, dirs = d["actions"][ex], d["directions"][ex]
+    assert all(len(set(r[:, 0])) == 7 for r in rows) and dirs[..., 1].min() >= 0 and dirs[..., 1].max() <= 4
+    assert any(len(set(r[:, 1])) < 7 for r in dirs)
+    obs_ex = np.stack([d["obs"][:, p] for p in range(2)], axis=1)[ex]
+    for o, r, dd in zip(obs_ex, rows, dirs):
+        for i in range(7):
+            assert r[i, 1] == oracle_mod.get_move(int(o[45 + 5 * r[i, 0]]) - 1, int(dd[i, 1]))
+    # unexplored rows are get_best_actions of the same inputs (smart_actions.npz holds them)
+    b = load_golden("smart_actions.npz")
+    assert np.array_equal(d["actions"][~ex], b["actions"][~ex]) and np.array_equal(d["directions"][~ex], b["directions"][~ex])
+    coin, sw, di = rng_spec.explore_draws(int(d["seed"][0]), 5, int(d["episode"][5]), int(d["obs"][5, 1, 0]), 1)
+    assert 0 <= coin < 2 ** 32 and len(set(sw)) == 7
