@@ -16,7 +16,7 @@ STAMPS_LIB_PATH = os.path.join(HERE, "libevg_stamps.so")  # `make -C csrc stamps
 NUM_PLAYERS, NUM_GROUPS, NUM_NODES, NUM_UNITS, NUM_ACTIONS, OBS_LEN = 2, 12, 11, 100, 7, 105
 MAX_SCORE = 3700
 OBS_F32, OBS_F64, OBS_I16 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 ERR_COMM = -6         # EVG_ERR_COMM: RCCL missing or one of its calls failed (evg_comm_*, evg_gather_returns)
 COMM_ID_BYTES = 128
 ERR_FAULT = -5        # EVG_ERR_FAULT: the handle's fault word is set (evg_check_fault)
@@ -28,7 +28,7 @@ POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, 
 
 EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat",
            "evg_random_actions_seat", "evg_smart_state_seat", "evg_smart_state_compact", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war",
-           "evg_sightings", "evg_smart_state", "evg_smart_actions", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies",
+           "evg_sightings", "evg_smart_state", "evg_smart_actions", "evg_smart_get_action", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies",
            "evg_scripted_actions", "evg_scripted_reset",
            "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats",
            "evg_episode_stats_device", "evg_pack_episode_results", "evg_pack_episode_results_counted", "evg_comm_unique_id", "evg_comm_init",
@@ -151,6 +151,7 @@ def load(path=None):
     L.evg_sightings.argtypes = [vp, vp, vp]
     L.evg_smart_state.argtypes = [vp, C.c_int, vp, vp, vp]
     L.evg_smart_actions.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.evg_smart_get_action.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     L.evg_move_table.argtypes = [vp]
     L.evg_move_table.restype = None
     L.evg_random_actions.argtypes = [vp, vp, vp]

@@ -748,6 +748,18 @@ int evg_smart_actions(evg_handle* h, int player, const void* obs, const float* q
     return EVG_OK;
 }
 
+int evg_smart_get_action(evg_handle* h, int seat, int obs_one_seat, const void* obs, const float* q, float epsilon, const float* epsilon_env,
+                         int32_t* actions_out, int32_t* directions_out, uint8_t* explored_out, void* stream) {
+    if (!h || !obs || !q || !actions_out || seat < 0 || seat > 1) return fail(EVG_ERR_INVALID, "bad argument");
+    if (!epsilon_env && !(epsilon >= 0.0f && epsilon <= 1.0f)) return fail(EVG_ERR_INVALID, "epsilon %g outside [0, 1]", (double)epsilon);
+    EVG_NEED_ALIGNED16(obs); EVG_NEED_ALIGNED16(q); EVG_NEED_ALIGNED16(actions_out); EVG_NEED_ALIGNED16(directions_out);
+    EVG_ON_DEVICE(h);
+    const SmartExplore ex{seat, epsilon, epsilon_env, explored_out};
+    const int rc = launch_smart_actions(h->S, seat, obs, obs_one_seat ? 1 : 0, q, actions_out, directions_out, h->cfg.obs_dtype, stream, &ex);
+    if (rc) return fail(EVG_ERR_HIP, "smart_get_action launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return EVG_OK;
+}
+
 void evg_move_table(int32_t* table /* [11][5] */) {
     // agents/Smart_State/Move_Translation.py:3-97: node reached from (0-indexed) node n0 in direction 0 left, 1 right, 2 up, 3 down, 4 stay
     static const int32_t T[5][11] = {{1, 1, 3, 1, 2, 3, 4, 5, 6, 7, 11}, {1, 5, 6, 7, 8, 9, 10, 11, 9, 11, 11}, {2, 2, 2, 3, 5, 6, 7, 8, 8, 9, 8},

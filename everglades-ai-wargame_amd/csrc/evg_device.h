@@ -187,9 +187,15 @@ int launch_fog(const DevState& S, uint8_t* fog, uint8_t* know, int8_t* sight, vo
 int launch_mt_seed(const DevState& S, const uint32_t* seeds_dev, void* stream);
 int launch_smart_state(const DevState& S, int player, const void* obs, int seat_only /* obs is [N][105] */, float* out,
                        float* out_swarm /* non-NULL: compact form, out = shared [N][34], out_swarm [N][12][13] */, int obs_dtype, void* stream);
+struct SmartExplore {            // evg_smart_get_action: the epsilon branch of DQNAgent.get_action on top of evg_smart_actions
+    int seat;                    // the agent's player number (keys its draws)
+    float eps;                   // epsilon of every env ...
+    const float* eps_env;        // ... unless this device array [N] is given
+    uint8_t* explored;           // device [N] or NULL
+};
 int launch_smart_actions(const DevState& S, int player, const void* obs, int seat_only /* obs is [N][105] */, const float* q, int32_t* actions,
                          int32_t* directions,
-                         int obs_dtype, void* stream);
+                         int obs_dtype, void* stream, const SmartExplore* explore = nullptr /* NULL: get_best_actions only */);
 int launch_pack_results(const DevState& S, float* out, long long* counts /* device [4] or NULL */, void* stream);
 
 }  // namespace evg

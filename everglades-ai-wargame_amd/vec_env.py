@@ -353,6 +353,34 @@ class EvergladesVecEnv(object):
             self._check(rc)
         return out
 
+    def smart_get_action(self, q, epsilon, seat=0, obs=None, out=None, directions=None, explored=None):
+        """DQNAgent.get_action on the device (evg_smart_get_action): per env the epsilon coin, then get_random_actions (7 distinct swarms, 7 directions with
+        replacement, get_move) or get_best_actions (smart_actions).  `epsilon`: a float in [0, 1] for every env, or a float32 tensor [N] with one per env.
+        `seat` is the agent's player number (it keys the draws); `obs` as in smart_actions.  `explored`: a uint8 tensor [N] that receives 1 where the random
+        branch ran.  Returns int32 [N, 7, 2] {swarm, node}, what step_vs() takes as `actions`."""
+        torch = _torch()
+        obs = self.obs if obs is None else obs
+        self._user(q, (self.num_envs, _lib.NUM_GROUPS, 5), torch.float32, "q")
+        if out is None:
+            self._seat_buffers()
+            out = self._actions_seat
+        self._user(out, (self.num_envs, _lib.NUM_ACTIONS, 2), self._int32, "out")
+        if directions is not None:
+            self._user(directions, (self.num_envs, _lib.NUM_ACTIONS, 2), self._int32, "directions")
+        if explored is not None:
+            self._user(explored, (self.num_envs,), torch.uint8, "explored")
+        one_seat = isinstance(obs, torch.Tensor) and obs.dim() == 2
+        self._user(obs, (self.num_envs, _lib.OBS_LEN) if one_seat else (self.num_envs, 2, _lib.OBS_LEN), self.obs_dtype, "obs")
+        eps_env = None
+        if isinstance(epsilon, torch.Tensor):
+            eps_env = self._user(epsilon, (self.num_envs,), torch.float32, "epsilon")
+            epsilon = 0.0
+        rc = self.L.evg_smart_get_action(self._h, int(seat), int(one_seat), C.c_void_p(obs.data_ptr()), C.c_void_p(q.data_ptr()), float(epsilon),
+                                         self._ptr(eps_env), C.c_void_p(out.data_ptr()), self._ptr(directions), self._ptr(explored), self._stream())
+        if rc:
+            self._check(rc)
+        return out
+
     @staticmethod
     def expand_smart_state(shared, swarm):
         """[N, 12, 59] from the compact pair (for checks; a consumer would rather split its first layer's weights)."""

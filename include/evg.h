@@ -36,8 +36,9 @@
 extern "C" {
 #endif
 
-#define EVG_ABI_VERSION 5
-/* 5: evg_smart_actions; evg_comm_unique_id / evg_comm_init / evg_gather_returns / evg_comm_destroy + EVG_ERR_COMM; every device buffer must be
+#define EVG_ABI_VERSION 6
+/* 6: evg_smart_get_action (DQNAgent.get_action with epsilon > 0); reward / score buffers need 8-byte alignment only (5 asked 16 of every buffer)
+ * 5: evg_smart_actions; evg_comm_unique_id / evg_comm_init / evg_gather_returns / evg_comm_destroy + EVG_ERR_COMM; every device buffer must be
  *    16-byte aligned (checked)
  * 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat, evg_smart_state_compact,
  *    evg_check_fault + EVG_ERR_FAULT, evg_pack_episode_results_counted, evg_config.cache_mib
@@ -241,6 +242,19 @@ EVG_API void evg_move_table(int32_t* table);
  * is a swarm's maximum, as in torch, and sorts like +inf).  With evg_smart_state(_seat / _compact) this closes the learner's turn on the device:
  * observation -> features -> (consumer's network) -> orders -> evg_step_vs_policy, no host or framework glue between the kernels. */
 EVG_API int evg_smart_actions(evg_handle* h, int player, const void* obs, const float* q, int32_t* actions_out, int32_t* directions_out, void* stream);
+/* The whole of DQNAgent.get_action (agents/Smart_State/DQNAgent.py:130-146): `sample = random.random(); if sample < self.epsilon:
+ * get_random_actions(obs) else get_best_actions(obs)`, i.e. evg_smart_actions plus the exploring branch (:148-173): swarms = np.random.choice(12, 7,
+ * replace=False), directions = np.random.choice(5, 7, replace=True), row i = {swarms[i], get_move(location of swarms[i] - 1, directions[i])}.  With it the
+ * learner's turn stays on the device during TRAINING (epsilon > 0) too.
+ *   seat            0 / 1: the agent's player number; with obs_one_seat == 0 its rows of obs [N][2][105] are read, with obs_one_seat != 0 obs is a
+ *                   one-seat tensor [N][105].  Only obs[0] (the turn, part of the key of the draws) and the swarm locations obs[45 + 5 s] are read.
+ *   epsilon         the exploring probability of every env, in [0, 1]; epsilon_env (device float [N], may be NULL) gives one per env instead.
+ *   actions_out / directions_out   as in evg_smart_actions;  explored_out  device uint8 [N] or NULL: 1 where the random branch was taken.
+ * The coin and the two choices are keyed draws like every other (oracle/rng_spec.py `explore_draws`, domain 4): one agent call =
+ * (seed, global env id, episode, turn = obs[0], seat) -- pinned against the reference's own get_action by tests/golden/smart_explore.npz.  The coin is a 32-bit
+ * fraction compared with epsilon in float64 (epsilon 0 never explores, epsilon 1 always). */
+EVG_API int evg_smart_get_action(evg_handle* h, int seat, int obs_one_seat, const void* obs, const float* q, float epsilon, const float* epsilon_env,
+                                 int32_t* actions_out, int32_t* directions_out, uint8_t* explored_out, void* stream);
 
 /* Input generator for the benchmark configs: the on-device equivalent of
  * agents/State_Machine/random_actions.py:38-46 for every env and both players, keyed by

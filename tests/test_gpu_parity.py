@@ -664,6 +664,74 @@ def test_smart_actions_match_reference_fixture_and_oracle(evg, oracle_mod):
     env.close()
 
 
+def test_smart_get_action_with_epsilon_matches_reference_fixture_and_oracle(evg, oracle_mod):
+    """The other half of the Smart_State agent's turn (evg_smart_get_action = DQNAgent.get_action, agents/Smart_State/DQNAgent.py:130-173): the epsilon
+    coin, then get_random_actions or get_best_actions.  (1) tests/golden/smart_explore.npz -- the reference's own get_action with its three draws served
+    from the keyed stream -- for every observation dtype, from the two-seat and from a one-seat tensor, epsilon per env; (2) a ragged 65 536 + 37-env batch
+    of mid-game observations (envs in different episodes after auto-resets) against the oracle with a scalar epsilon of 0.1 and with per-env epsilons, both
+    seats; (3) epsilon 0 is evg_smart_actions, epsilon 1 explores everywhere; (4) the rows feed step_vs()."""
+    import torch
+    d = load_golden("smart_explore.npz")
+    M = d["obs"].shape[0]
+    for dt, tdt in (("float32", torch.float32), ("float64", torch.float64), ("int16", torch.int16)):
+        env = evg.EvergladesVecEnv(M, seed=int(d["seed"][0]), obs_dtype=dt, auto_reset=False)
+        env.reset()
+        st = env.get_state()
+        st["env"][:, 2] = d["episode"]                        # the agents of the fixture live in episodes m % 3 (part of the key of their draws)
+        env.set_state(st["groups"], st["nodes"], st["health"], st["env"])
+        obs = torch.as_tensor(d["obs"].astype(np.int64), device=env.device).to(tdt).contiguous()
+        for p in range(2):
+            q = torch.as_tensor(d["q"][:, p], device=env.device).contiguous()
+            eps = torch.as_tensor(d["eps"][:, p], device=env.device).contiguous()
+            dirs = torch.zeros((M, 7, 2), dtype=torch.int32, device=env.device)
+            ex = torch.zeros(M, dtype=torch.uint8, device=env.device)
+            a = env.smart_get_action(q, eps, seat=p, obs=obs, directions=dirs, explored=ex)
+            assert np.array_equal(_np(ex), d["explored"][:, p]), (dt, p)
+            assert np.array_equal(_np(a), d["actions"][:, p]) and np.array_equal(_np(dirs), d["directions"][:, p]), (dt, p)
+            a1 = env.smart_get_action(q, eps, seat=p, obs=obs[:, p].contiguous(), out=torch.zeros((M, 7, 2), dtype=torch.int32, device=env.device))
+            assert np.array_equal(_np(a1), d["actions"][:, p]), (dt, p, "one-seat")
+        env.close()
+    N, seed = 65536 + 37, 12
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, env_id_base=1000)
+    env.reset()
+    env.rollout_policies(93, "cycle_rush_turn25", "swarm", fused=True, turns_per_launch=93)       # BaseCapture on turns 91-95: envs are in episodes 0 and 1
+    obs = _np(env.obs).astype(np.float64)
+    episodes = env.get_state()["env"][:, 2].astype(np.uint32)
+    assert len(np.unique(episodes)) >= 2 and len(np.unique(obs[:, 0, 0])) >= 3
+    ids = (1000 + np.arange(N)).astype(np.uint32)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for p in range(2):
+        q = (torch.randn((N, 12, 5), generator=g) * 2.0).round().div(2.0).to(env.device)
+        for eps_np in (np.full(N, 0.1, np.float32), np.random.default_rng(p).random(N).astype(np.float32)):
+            scalar = bool((eps_np == eps_np[0]).all())
+            eps = float(eps_np[0]) if scalar else torch.as_tensor(eps_np, device=env.device)
+            dirs = torch.zeros((N, 7, 2), dtype=torch.int32, device=env.device)
+            ex = torch.zeros(N, dtype=torch.uint8, device=env.device)
+            got = _np(env.smart_get_action(q, eps, seat=p, directions=dirs, explored=ex))
+            want_a, want_d, want_x = oracle_mod.smart_get_action(_np(q), obs[:, p], seed, ids, episodes, p, eps_np)
+            assert np.array_equal(_np(ex), want_x) and np.array_equal(got, want_a) and np.array_equal(_np(dirs), want_d), (p, scalar)
+            if scalar:
+                assert abs(want_x.mean() - 0.1) < 0.005                                             # the coin is a fair 10 % over 65 573 agents
+        best = _np(env.smart_actions(q, p)).copy()
+        assert np.array_equal(_np(env.smart_get_action(q, 0.0, seat=p)), best)
+        ex = torch.zeros(N, dtype=torch.uint8, device=env.device)
+        rnd = _np(env.smart_get_action(q, 1.0, seat=p, explored=ex))
+        assert _np(ex).all() and (np.sort(rnd[:, :, 0], axis=1)[:, 1:] != np.sort(rnd[:, :, 0], axis=1)[:, :-1]).all()   # 7 distinct swarms everywhere
+    sobs = env.observe_seat(1)
+    feats = env.smart_state(1, sobs)
+    w = torch.randn((59, 5), generator=g).to(env.device)
+    rows = env.smart_get_action((feats @ w).contiguous(), 0.3, seat=1, obs=sobs)
+    want_a, _, _ = oracle_mod.smart_get_action(_np(feats @ w), _np(sobs).astype(np.float64), seed, ids, episodes, 1, np.full(N, 0.3, np.float32))
+    assert np.array_equal(_np(rows), want_a)
+    o2, rew, done, info = env.step_vs("cycle_rush_turn25", rows, seat=1)
+    assert o2.shape == (N, 105) and int(info["status"].max()) <= 3
+    with pytest.raises(evg.EvgError):
+        env.smart_get_action(q, 1.5, seat=0)
+    with pytest.raises(ValueError):
+        env.smart_get_action(q, torch.zeros(N - 1, device=env.device), seat=0)
+    env.close()
+
+
 @pytest.mark.parametrize("tpl", [2, 7, 150])
 def test_persistent_multi_turn_rollout_equals_stepwise(evg, oracle_mod, tpl):
     """The persistent rollout form (each launch plays `tpl` consecutive turns per wavefront with the state resident on
