@@ -293,9 +293,14 @@ def test_bench_times_the_region_several_times_and_reports_the_median():
     spec.loader.exec_module(bench)
     assert bench.repeats_for(20) == 9 and bench.repeats_for(450) == 9 and bench.repeats_for(2499) == 9 and bench.repeats_for(2500) == 1 and bench.repeats_for(100000) == 1
     assert bench.repeats_for(20, forced=1) == 1 and bench.repeats_for(100000, forced=3) == 3
-    assert bench.median_region([5.0]) == 0
-    assert bench.median_region([0.41, 0.37, 0.36, 0.39, 0.36, 0.35, 0.40, 0.38, 0.42]) == 7        # 0.38: four regions below, four above
-    assert bench.median_region([3.0, 1.0, 2.0, 4.0]) == 2                                              # even count: the lower middle one
+    assert bench.median_regions([5.0]) == [0]
+    assert bench.median_regions([0.41, 0.37, 0.36, 0.39, 0.36, 0.35, 0.40, 0.38, 0.42]) == [7]      # 0.38: four regions below, four above
+    assert bench.median_regions([3.0, 1.0, 2.0, 4.0]) == [2, 0]                                        # even count: BOTH middle ones, 2.0 and 3.0 ...
+    s = bench.summarise_regions([3.0, 1.0, 2.0, 4.0], [30.0, 10.0, 20.0, 40.0], [None] * 4, steps=10, total=100)
+    assert s["seconds"] == 2.5 and s["kernel_ms_sum"] == 25.0 and s["collective_ms"] is None         # ... and the line reports their mean (a true median)
+    assert s["timing"]["reported"] == "mean of the two middle regions" and s["timing"]["min_value"] == 250.0 and s["timing"]["max_value"] == 1000.0
+    s = bench.summarise_regions([0.3, 0.1, 0.2], [3.0, 1.0, 2.0], [0.03, 0.01, 0.02], steps=20, total=65536)
+    assert s["median_indices"] == [2] and s["seconds"] == 0.2 and s["kernel_ms_sum"] == 2.0 and s["collective_ms"] == 0.02
 
 
 def test_bench_stdout_line_is_compact_and_complete():
@@ -328,8 +333,8 @@ def test_bench_stdout_line_is_compact_and_complete():
         # carries SURVEY 8(d)'s byte model priced at the same kernel time (above 1: not applicable to a design that keeps the state on chip), and how the
         # region was timed
         assert c["roofline"]["bound"] in ("fabric", "hbm") and c["roofline"]["survey_8d_frac"] > 0
-        if c["roofline"]["bound"] == "fabric":
-            assert c["roofline"]["bound_contract"] == "hbm" and "bound_is" in c["roofline"]
+        if "bound_detail" in c["roofline"]:          # round 6: `bound` is always the contract's value, the qualifier is a field of its own
+            assert c["roofline"]["bound"] == "hbm" and c["roofline"]["bound_detail"] == "fabric" and "bound_detail_is" in c["roofline"]
         if full["config"]["envs_per_gpu"] == 65536 and full["config"]["workload"].startswith("65536 concurrent DemoMap games per GPU, random") and "float32" in full["config"]["workload"]:
             assert 0.3 < c["roofline"]["hbm_proper_frac"] < 0.9 and "cycled" in c["roofline"]["hbm_proper_source"]
             if "rehearse" not in f:                                   # (two gloo ranks share one GPU: that line's own fraction says nothing)
@@ -470,3 +475,88 @@ def test_tables_from_json_refuses_what_the_reference_would_play_differently(evg,
     u["units"].append(dict(u["units"][0], Name="Fifth"))
     with pytest.raises(ValueError):
         evg.tables_from_json(good_map, write("bad_u5.json", u))
+
+
+def _load_bench(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_roofline_pricing_from_a_saved_counter_pass():
+    """bench.py's hbm_roofline is a pure function of a committed counter summary and the measured times: priced here against the saved pass
+    profiles/r05_d_pmc_traffic.json with hand-computed expectations, incl. the re-scaling of the state round trip to the turns per launch that were timed,
+    the two time bases (`frac` from the ms_per_step of the region `value` comes from, `frac_kernel_events` from the launches' own HIP-event time) and the
+    fallback to the unavoidable output bytes when profiles/ holds no pass of the running build (a lower bound, and the object says so)."""
+    bench = _load_bench("evg_bench_roof")
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_d_pmc_traffic.json")))
+    pmc["_file"] = "profiles/r05_d_pmc_traffic.json"
+    form = pmc["forms"]["persistent"]
+    n = 65536
+    for tpl_timed in (150.0, 20.0):
+        bpe = form["bytes_per_env_step_steady"] + form["state_round_trip_bytes_per_env"] / tpl_timed
+        r = bench.hbm_roofline(pmc, "persistent", 0.0150, tpl_timed, n, "float32", "random", "abc", region_ms_per_step=0.0160)
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+        assert abs(r["bytes_per_env_step"] - bpe) < 1e-9 and r["bytes_source"] == "profiles/r05_d_pmc_traffic.json [persistent]"
+        assert abs(r["achieved"] - bpe * n / 0.0160e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+        assert abs(r["achieved_kernel_events"] - bpe * n / 0.0150e-3 / 1e9) < 1e-6 and r["frac_kernel_events"] > r["frac"]
+        assert abs(r["traffic"] - bpe * n * tpl_timed) < 1e-3 and r["traffic_unit"] == "bytes per launch"
+        assert 1300 < r["algorithmic_bytes_per_env_step"] < 1400 and 1.0 < r["traffic_over_algorithmic"] < 1.15      # DESIGN section 6: 971 + 2 x rows written
+    assert 1400 < bench.hbm_roofline(pmc, "persistent", 0.015, 150.0, n, "float32")["bytes_per_env_step"] < 1450         # the r05 figure: 1 425 B
+    # a per-turn leg prices its stream time: both pairs are the same figure
+    r = bench.hbm_roofline(pmc, "learner_vs_bot_per_turn", 0.030, 1, n, "float32")
+    assert r["frac"] == r["frac_kernel_events"] and r["mandatory_output_bytes_per_env_step"] == 420 + 112 + 19
+    # no pass of this build: the mandatory outputs, a lower bound, traffic null
+    r = bench.hbm_roofline(None, "persistent", 0.0150, 150.0, n, "float32", "random", "deadbeef", region_ms_per_step=0.0160)
+    assert r["traffic"] is None and r["bytes_per_env_step"] == 971 and "lower bound" in r["bytes_source"] and "deadbeef" in r["bytes_source"]
+    assert abs(r["frac"] - 971 * n / 0.0160e-3 / 1e9 / 8000.0) < 1e-12
+    # committed_counters() refuses a pass of another build (hash mismatch) -- what makes the fallback above happen
+    assert bench.committed_counters("pmc_traffic", 65536, "random", "float32") is None or \
+        bench.committed_counters("pmc_traffic", 65536, "random", "float32")["kernel_source_hash"] == bench.kernel_source_hash()
+    # cache-resident working set: `bound` stays the contract's "hbm", the qualifier is a field of its own
+    roof = bench.mark_cache_resident({"bound": "hbm"}, pmc, n, "float32")
+    assert roof["bound"] == "hbm" and roof["bound_detail"] == "fabric"
+    assert "bound_detail" not in bench.mark_cache_resident({"bound": "hbm"}, None, n, "float32")
+    assert bench.round_working_set_bytes(262144, "float32") == bench.round_working_set_bytes(65536, "float32") < (256 << 20)
+    cyc = json.load(open(os.path.join(ROOT, "profiles", "r05_d_262144envs_cycled_pmc_traffic.json")))
+    cyc["_file"] = "profiles/r05_d_262144envs_cycled_pmc_traffic.json"
+    bm, fields = bench.beyond_the_cache(pmc, None, cyc, None, "float32")
+    assert 0.4 < fields["hbm_proper_frac"] < 0.7 and "cycled" in fields["hbm_proper_source"] and bm["diag_library_chunked_over_262144_envs"]["working_set_MB"] > 600
+    assert bench.beyond_the_cache(None, None, cyc, None, "float32") == (None, {})
+    sq = json.load(open(os.path.join(ROOT, "profiles", "r05_d_sq_counters.json")))
+    sq["_file"] = "profiles/r05_d_sq_counters.json"
+    v = bench.valu_roofline(sq, "persistent", n, 0.0141)
+    assert 0.6 < v["frac"] < 0.85 and v["valu_insts_per_wave_turn"] > 2500 and bench.valu_roofline(None, "persistent", n, 0.0141) is None
+
+
+def test_bench_line_says_where_every_rank_sat_and_what_the_reference_does():
+    """The first multi-GPU line must prove itself (N ranks on N distinct GPUs), and a reader of the compact line must see the long region, the cold figure
+    and the Python reference's own rate: compact_line() of a synthetic full object keeps all of them within the size a driver is known to capture."""
+    bench = _load_bench("evg_bench_ident")
+    ids = [dict(local_rank=r, device_index=r, name="AMD Instinct MI355X", pci="0000:%02x:00" % (5 + r), uuid="GPU-%04d" % r) for r in range(8)]
+    assert bench.check_distinct_devices(ids, "nccl", False) == {"distinct_devices": True, "identified_by": "uuid", "devices_seen": 8}
+    no_uuid = [dict(i, uuid=None) for i in ids]
+    assert bench.check_distinct_devices(no_uuid, "nccl", False)["identified_by"] == "pci"
+    twice = [ids[0], dict(ids[0], local_rank=1)]
+    with pytest.raises(SystemExit):
+        bench.check_distinct_devices(twice, "nccl", False)                     # two RCCL ranks on one GPU: not a one-rank-per-GPU run
+    assert bench.check_distinct_devices(twice, "gloo", True) == {"distinct_devices": False, "identified_by": "uuid", "devices_seen": 1}   # a rehearsal records it
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_d_bench_rehearse_rccl_1rank.json")))
+    full["value_cold"], full["value_protocol"] = 3.2e9, "..."
+    full["sustained"] = dict(turns=450, launches=3, turns_per_launch=150, region_ms=6.41, ms_per_step=0.01424, value=4.6e9, kernel_ms=0.0141, what="...")
+    full["cpu_baseline"] = dict(full.get("cpu_baseline") or dict(value=9.6e6, unit="env-steps/s", cores=16, kind="port", obs_dtype="float64", sample="8192 envs x 1 turns (random vs random"),
+                                reference_python_env_steps_per_s=list(bench.REFERENCE_PYTHON_ENV_STEPS_PER_S), reference_python_source="BASELINE.md section 2 ...")
+    d = full["distributed"]
+    d["per_rank"] = [dict(p, **ids[i]) for i, p in enumerate(d["per_rank"])]
+    d.update(bench.check_distinct_devices(ids[:len(d["per_rank"])], "nccl", True), rccl_ranks_seen=1, evg_comm_ranks=None)
+    c = json.loads(json.dumps(bench.compact_line(full), separators=(",", ":")))
+    assert c["value_cold"] == 3200000000 and c["sustained"]["turns"] == 450 and c["sustained"]["region_ms"] == 6.41 and c["sustained"]["value"] == 4600000000
+    assert c["cpu_baseline"]["reference_python_env_steps_per_s"] == [529, 554] and c["cpu_baseline"]["kind"] == "port"
+    pr = c["distributed"]["per_rank"]
+    assert pr["local_rank"] == [0] and pr["device_index"] == [0] and pr["pci"] == ["0000:05:00"] and c["distributed"]["device_names"] == ["AMD Instinct MI355X"]
+    assert c["distributed"]["distinct_devices"] is True and c["distributed"]["rccl_ranks_seen"] == 1
+    # eight ranks still fit
+    d["per_rank"] = [dict(d["per_rank"][0], **ids[i], rank=i) for i in range(8)]
+    assert len(json.dumps(bench.compact_line(full), separators=(",", ":"))) < 5200

@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 for FORM in ${FORMS:-persistent perturn caller learner}; do
   if [ $FORM = persistent ]; then TPL=150; else TPL=1; fi
   EXTRA=""; if [ $FORM = caller ]; then EXTRA="--caller-actions"; fi; if [ $FORM = learner ]; then EXTRA="--learner-seat"; fi
-  CMD="python3 $R/bench.py --steps 150 --warmup 150 --repeats 1 --no-cpu-baseline --no-extra-legs --turns-per-launch $TPL $EXTRA $*"
+  CMD="python3 $R/bench.py --steps 150 --warmup 150 --repeats 1 --sustained-launches 0 --no-cpu-baseline --no-extra-legs --turns-per-launch $TPL $EXTRA $*"
   echo "$CMD" > $OUT/cmd_$FORM.txt
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${FORM}_stats -- $CMD > $OUT/bench_${FORM}_stats.json 2> $OUT/${FORM}_stats.err || exit 1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${FORM}_fetch -- $CMD > $OUT/bench_${FORM}_fetch.json 2> $OUT/${FORM}_fetch.err || exit 1

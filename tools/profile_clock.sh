@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/clock_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/p -- python3 $R/bench.py --steps 150 --warmup 150 --repeats 1 --no-cpu-baseline --no-extra-legs > $OUT/bench.json 2> $OUT/err.txt || exit 1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/p -- python3 $R/bench.py --steps 150 --warmup 150 --repeats 1 --sustained-launches 0 --no-cpu-baseline --no-extra-legs > $OUT/bench.json 2> $OUT/err.txt || exit 1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/p/*/*_counter_collection.csv")[0]

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for FORM in persistent perturn; do
   if [ $FORM = persistent ]; then TPL=150; else TPL=1; fi
-  rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/$FORM -- python3 $R/bench.py --steps 150 --warmup 150 --repeats 1 --no-cpu-baseline --no-extra-legs --turns-per-launch $TPL > $OUT/bench_$FORM.json 2> $OUT/$FORM.err || exit 1
+  rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/$FORM -- python3 $R/bench.py --steps 150 --warmup 150 --repeats 1 --sustained-launches 0 --no-cpu-baseline --no-extra-legs --turns-per-launch $TPL > $OUT/bench_$FORM.json 2> $OUT/$FORM.err || exit 1
 done
 python3 - <<PY
 import csv, glob

@@ -15,7 +15,7 @@ P3="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA
 for FORM in ${FORMS:-persistent perturn learner}; do
   if [ $FORM = persistent ]; then TPL=150; else TPL=1; fi
   EXTRA=""; if [ $FORM = learner ]; then EXTRA="--learner-seat"; fi
-  CMD="python3 $R/bench.py --steps 150 --warmup 150 --repeats 1 --no-cpu-baseline --no-extra-legs --turns-per-launch $TPL $EXTRA $*"
+  CMD="python3 $R/bench.py --steps 150 --warmup 150 --repeats 1 --sustained-launches 0 --no-cpu-baseline --no-extra-legs --turns-per-launch $TPL $EXTRA $*"
   echo "$CMD" > $OUT/cmd_$FORM.txt
   rocprofv3 --kernel-trace --pmc $P1 --output-format csv -d $OUT/${FORM}_p1 -- $CMD > $OUT/bench_${FORM}_p1.json 2> $OUT/${FORM}_p1.err || exit 1
   rocprofv3 --kernel-trace --pmc $P2 --output-format csv -d $OUT/${FORM}_p2 -- $CMD > $OUT/bench_${FORM}_p2.json 2> $OUT/${FORM}_p2.err || exit 1
