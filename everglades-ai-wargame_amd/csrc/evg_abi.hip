@@ -160,8 +160,8 @@ static int check_fault(evg_handle* h, uint32_t* word_out = nullptr) {
     if (fault)
         return fail(EVG_ERR_FAULT,
                     "a chunked rollout launch failed to hand a set of envs on (fault word %u: 1 = a workgroup gave up waiting for a predecessor chunk, "
-                    "2 = a workgroup ran on an XCD the create-time probe did not see, 4 = a queue of a chunked launch was not drained): the state and "
-                    "the results of this handle are not valid; destroy it",
+                    "2 = a workgroup ran on an XCD the create-time probe did not see, 4 = a queue of a chunked launch was not drained, 8 = a hand-over "
+                    "delivered stale state words (checksum mismatch)): the state and the results of this handle are not valid; destroy it",
                     fault);
     return EVG_OK;
 }
@@ -512,6 +512,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     // 16 queue counters on lines of their own (the create-time XCD probe borrows the 1 024 words) ...
     if (!rc) rc = dev_alloc(h, &S.queue, 1024 + (N + 31) / 32 + 1);
     if (!rc) S.progress = S.queue + 1024;                                // ... and the per-set progress flags behind them: one memset zeroes both
+    if (!rc) rc = dev_alloc(h, &S.handoff, 2 * N);                        // per-lane hand-over checksums of chunked launches (written before they are read)
     if (!rc) rc = dev_alloc(h, &S.fault, 1);
     if (!rc) {        // host-mapped mirror of "the fault word is not zero" (check_fault)
         void* hp = nullptr;
@@ -540,7 +541,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     {
         // The chunked form's hand-over (evg_kernels.hip, "WHAT THIS RELIES ON") assumes ordinary coarse-grained device memory, cached in the L2 of the XCD
         // that touches it: refuse to run on anything else (managed or host memory behind these pointers) instead of corrupting state silently.
-        const void* must_be_device[] = {S.grp, S.stamp, S.node, S.env, S.episode, S.health, S.ep_ret, S.fin_ret, S.fin_len, S.fin_win, S.progress};
+        const void* must_be_device[] = {S.grp, S.stamp, S.node, S.env, S.episode, S.health, S.ep_ret, S.fin_ret, S.fin_len, S.fin_win, S.progress, S.handoff};
         for (const void* q : must_be_device) {
             hipPointerAttribute_t at;
             const hipError_t ae = hipPointerGetAttributes(&at, q);
@@ -1072,7 +1073,9 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
 #ifdef EVG_DIAG
 /* Diagnostic libraries only (libevg_diag.so / libevg_stamps.so; declared in no public header).
  *   ablate          bit0 orders, bit1 combat, bit2 movement, bit4 observation write-out, bit5 state store are skipped; bit6: a chunked launch never
- *                   publishes the first chunk of its first set (the fault path: its successor gives up after ~1 s and flags the handle)
+ *                   publishes the first chunk of its first set (the fault path: its successor gives up after ~5 s and flags the handle); bit7: chunks are
+ *                   published with an agent-scope release; bits 8-23: stagger knobs; bit24: the first chunk of a chunked launch's first set withholds its group
+ *                   words but hands on their checksum (the stale-data path: the consumer's checksum over what it loaded differs -> fault bit 3)
  *   lanes_per_wave  0 (default: what the product library launches), 2 (experiment: persistent rollouts of a batch beyond what the device holds run the
  *                   CHUNKED form over the whole batch, i.e. with a working set larger than the Infinity Cache), 64 (the two-lanes-per-env kernel at every batch
  *                   size and in both

@@ -107,9 +107,12 @@ struct DevState {
     uint32_t* progress;          // [ceil(N / 32)] chunked persistent launches: set s of 32 envs has finished chunk c of the launch <=> progress[s] == c + 1
     uint32_t* queue;             // [1024] chunked launches: next unit of each XCD's queue, one counter per 256-byte line.  queue and progress are ONE
                                  // allocation (queue first), zeroed by one memset on the stream before every chunked launch
+    uint32_t* handoff;           // [2][N] chunked launches: what a lane handed on at the end of its chunk -- a checksum over (chunk number, every state word it
+                                 // stored); the lane that takes the set's next chunk recomputes it over the words it LOADED (fault bit 3 on a mismatch)
     uint32_t* fault;             // [1] bit 0: a wave gave up waiting for a predecessor chunk; bit 1: a workgroup ran on an XCD the create-time probe did
                                  // not see;
-                                 // bit 2: a queue of a chunked launch was not drained (evg_chunk_verify_kernel, on the stream behind every chunked launch).
+                                 // bit 2: a queue of a chunked launch was not drained (evg_chunk_verify_kernel, on the stream behind every chunked launch);
+                                 // bit 3: a chunk hand-over delivered state words that are not the ones its producer stored (checksum mismatch: stale data).
                                  // Never expected; sticky; read by the pack kernel (poisoned rows) and by every host path on which results leave the handle
     uint32_t* fault_seen;        // [1] host-mapped mirror: set to 1 (plain store) together with any bit of `fault`, so that the host checks cost no device copy
     uint64_t  xcd_rank;          // nibble x = rank of XCC id x among the XCDs of this device (15 = not seen by the probe at evg_create)

@@ -371,7 +371,8 @@ EVG_API int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, in
 /* The handle's fault word (synchronises the device).  Chunked persistent rollout launches (batches beyond what the device holds at once,
  * evg_launch_plan) hand sets of envs from workgroup to workgroup; the word records: 1 = a workgroup gave up waiting for a predecessor
  * chunk (bounded wait, about 5 s), 2 = a workgroup ran on an XCD the create-time probe did not see, 4 = a queue of a chunked launch was
- * not drained (checked on the stream after every chunked launch).  None is expected ever; all mean that state and results of the
+ * not drained (checked on the stream after every chunked launch), 8 = a hand-over delivered STALE state: every lane hands on a checksum over the chunk number
+ * and every state word it stored, and the lane that takes the set's next chunk recomputes it over the words it loaded.  None is expected ever; all mean that state and results of the
  * handle are not valid.  The word is STICKY: evg_reset / evg_set_state do not clear it -- destroy the handle.  Returns EVG_OK or
  * EVG_ERR_FAULT (message in evg_last_error); *fault_out (may be NULL) receives the word.  Every path on which results leave the
  * handle checks it too: evg_episode_stats, evg_episode_stats_device and evg_get_state fail with EVG_ERR_FAULT, a timed rollout call

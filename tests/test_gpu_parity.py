@@ -3,6 +3,7 @@
 reference and (b) the CPU oracle on the same seeded inputs.  Bit-exact for every integer
 (observations, scores, status, packed state) and for float64 health; float32 rewards within 1e-6
 of the oracle's float64 (tolerance of BASELINE.json north_star: 1e-5)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -1922,6 +1923,54 @@ def test_a_lost_chunk_hand_over_ends_the_launch_and_is_reported(evg):
     w = _np(ok.packed_episode_results(counts=counts))[:, 2]
     assert (w >= 0).all() and _np(counts).tolist() == [int((w == k).sum()) for k in (0, 1, 2)] + [0]      # the pack kernel's own win bookkeeping of its rows
     ok.close()
+
+
+def test_a_stale_chunk_hand_over_is_reported(evg, oracle_mod):
+    """The chunked form's hand-over is cheaper than what the memory model asks for (store drain + relaxed flag inside one XCD's L2 instead of an agent-scope
+    release; step_kernel.inc says what it relies on).  If that ever failed to deliver the producer's LATEST words, the consumer must notice: every lane hands
+    on a checksum over (chunk number, every state word it stored) and the lane that takes the set's next chunk recomputes it over the words it LOADED.
+    Simulated through the diagnostic library (ablate bit 24): the first chunk of the launch's first set keeps its group words to itself -- memory still holds
+    the words of the chunk's start, exactly what a stale line would serve -- while flag and checksum are published as usual.  The consumer flags the handle
+    (fault bit 3 = 8; sticky; visible wherever results leave the handle); without the knob the same launches are clean and equal the oracle's games."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    N = 32 * 8 * cus + 2048
+    env = evg.EvergladesVecEnv(N, seed=5, auto_reset=True, library=evg._lib.DIAG_LIB_PATH, diag=dict(ablate=1 << 24))
+    assert "chunked" in env.launch_plan(150)[1]
+    env.reset()
+    assert env.check_fault() == 0
+    env.rollout_random(150, turns_per_launch=150)
+    torch.cuda.synchronize()
+    with pytest.raises(evg.EvgFault, match="stale state words"):
+        env.check_fault()
+    word = C.c_uint32(0)
+    assert env.L.evg_check_fault(env._h, C.byref(word)) == evg._lib.ERR_FAULT and word.value == 8           # only the stale-data bit
+    with pytest.raises(evg.EvgFault):
+        env.get_state()
+    assert (_np(env.packed_episode_results())[:, 2] == -2).all()                                            # poisoned rows: nothing leaves unnoticed
+    env.close()
+    # the same library and launches without the knob: no fault, and the games are the oracle's -- also for the scripted bots, whose agent words are part of
+    # what is handed on and summed
+    for policies in (None, ("cycle_rush_turn25", "swarm")):
+        ok = evg.EvergladesVecEnv(N, seed=5, auto_reset=True, library=evg._lib.DIAG_LIB_PATH)
+        ora = oracle_mod.Oracle(N, seed=5, auto_reset=True)
+        ok.reset()
+        o_obs = ora.reset()
+        P = evg.EvergladesVecEnv.POLICIES
+        oa = np.zeros((N, 2, 7, 2), np.int32)
+        if policies is None:
+            ok.rollout_random(60, turns_per_launch=60)
+            for _ in range(60):
+                ora.step_noobs(ora.random_actions())
+        else:
+            ok.rollout_policies(60, policies[0], policies[1], fused=True, turns_per_launch=60)
+            for _ in range(60):
+                ora.scripted_actions(P[policies[0]], 0, o_obs, oa)
+                ora.scripted_actions(P[policies[1]], 1, o_obs, oa)
+                o_obs, _, _, _ = ora.step(oa)
+        assert ok.check_fault() == 0
+        check_state(ok, ora.get_state(), "chunked hand-over, checksum clean")
+        ok.close()
 
 
 @pytest.mark.parametrize("variant", ["float64", "int16", "float32-release"])
