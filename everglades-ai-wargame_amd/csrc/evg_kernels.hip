@@ -207,7 +207,7 @@ int query_device_caps(int device_id, int obs_dtype, DeviceCaps* caps) {
 // 256 MiB on a whole MI355X, + 2 %): measured, us per turn, chunked / the alternative: 98 304 envs (270 MB) 25.8 / 27.5; 104 448 envs
 // (287 MB) 32.5 / ~29.5.
 long long rollout_bytes_per_env(const StepIO& io, int obs_dtype) {
-    long long b = kStateBytesPerEnv + 13 /* fin_ret, fin_len, fin_win */ + 19 /* reward, done, winner, scores, status */;
+    long long b = kStateBytesPerEnv + 13 /* fin_ret, fin_len, fin_win */ + 19 /* reward, done, winner, scores, status */ + 8 /* hand-over checksums */;
     if (io.obs) b += OBS2 * (obs_dtype == EVG_OBS_F64 ? 8 : (obs_dtype == EVG_OBS_I16 ? 2 : 4));
     if (io.actions_out) b += 2 * NA * 2 * 4;
     if (io.gen_actions == 2) b += 24;                    // the scripted agents' objects
@@ -397,7 +397,9 @@ int launch_smart_state(const DevState& S, int player, const void* obs, int seat_
 // network output -> orders: one DPP row (16 lanes) per env
 int launch_smart_actions(const DevState& S, int player, const void* obs, int seat_only, const float* q, int32_t* actions, int32_t* directions, int obs_dtype,
                          void* stream, const SmartExplore* ex) {
-    const dim3 grid((unsigned)(((size_t)S.N * 16 + 255) / 256)), block(256);
+    // (the exploring form draws per env in the first wavefront of 1 024-thread workgroups = 64 envs: side_kernels.inc)
+    const unsigned threads = ex ? 1024u : 256u;
+    const dim3 grid((unsigned)(((size_t)S.N * 16 + threads - 1) / threads)), block(threads);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int2* a = reinterpret_cast<int2*>(actions);
     int2* d = reinterpret_cast<int2*>(directions);

@@ -405,7 +405,12 @@ EVG_API int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t*
  *                        send / receive.  recv_out: on rank `root` device float [sum(counts)][4], 16-byte aligned -- the rows {return p0, return p1,
  *                        winner, length} of ALL envs in global env order --, NULL on every other rank.  A rank whose handle is faulted sends poisoned rows
  *                        (winner -2), as evg_pack_episode_results does
- *   evg_comm_destroy     releases the communicator (evg_destroy does it as well) */
+ *   evg_comm_destroy     releases the communicator (evg_destroy does it as well)
+ * ERRORS OF THESE CALLS ARE FATAL FOR THE WHOLE JOB.  evg_comm_init and evg_gather_returns validate their arguments (and RCCL's presence) BEFORE they enter
+ * the collective: a rank that fails there returns its error at once while every other rank is already inside ncclCommInitRank / waiting for that rank's rows,
+ * where RCCL has no timeout.  A caller must therefore treat any non-zero return of evg_comm_* / evg_gather_returns on ANY rank as the end of the job (tear the
+ * process group down, e.g. let the launcher kill the ranks), never retry or continue on the ranks that succeeded; ranks agree on arguments that can differ
+ * (counts, world, root) over their own channel before calling. */
 #define EVG_COMM_ID_BYTES 128
 EVG_API int evg_comm_unique_id(void* id_out);
 EVG_API int evg_comm_init(evg_handle* h, const void* id, int world, int rank, const int32_t* counts);

@@ -560,3 +560,52 @@ def test_bench_line_says_where_every_rank_sat_and_what_the_reference_does():
     # eight ranks still fit
     d["per_rank"] = [dict(d["per_rank"][0], **ids[i], rank=i) for i in range(8)]
     assert len(json.dumps(bench.compact_line(full), separators=(",", ":"))) < 5200
+
+
+def test_both_lane_mappings_cite_the_same_reference_lines():
+    """csrc/evg_step4.inc (four lanes per env) is a hand-maintained second copy of the turn next to the two-lane fragments (step_orders / step_combat /
+    step_move_capture / step_outputs .inc).  The parity suite keeps their RESULTS equal on the GPU; this table-driven check keeps their STRUCTURE comparable on
+    the CPU: both walk through the phase markers PHASE(1) .. PHASE(13) in the same order, and between the same two markers both cite the same anchor ranges of
+    the reference (server.py / everglades_env.py line ranges in the comments) -- so a rule that moves or is re-derived in one copy shows up as a mismatch here."""
+    csrc = os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc")
+    two = "".join(open(os.path.join(csrc, f)).read() for f in ("step_orders.inc", "step_combat.inc", "step_move_capture.inc", "step_outputs.inc"))
+    four = open(os.path.join(csrc, "evg_step4.inc")).read()
+    four = four[four.index("if (MULTI) { PHASE(0); }"):]                  # the turn loop (the prologue's STAMP(0) / PHASE(0) belong to step_kernel.inc there)
+
+    def phases(src):
+        parts = re.split(r"PHASE\((\d+)\);", src)
+        order, text, prev = [], {}, parts[0]
+        for i in range(1, len(parts), 2):
+            k = int(parts[i])
+            order.append(k)
+            text[k] = prev
+            prev = parts[i + 1]
+        return order, text
+
+    def cited(text):
+        out = set()
+        for line in text.split("\n"):
+            if "//" in line:
+                for m in re.finditer(r"(?:\.py)?:(\d{2,3})(?:-(\d{2,3}))?\b", line.split("//", 1)[1]):
+                    a, b = int(m.group(1)), int(m.group(2) or m.group(1))
+                    if b >= a:
+                        out.add((a, b))
+        return out
+
+    # phase k = the code in front of PHASE(k): what it implements in the reference
+    anchors = {2: [(218, 271)],                                    # order application, server.py:218-271
+               3: [(503, 654)],                                    # combat (stage 0: who fights), server.py:503-654
+               5: [(549, 566)],                                    # the draws and the infliction table, :549-566
+               6: [(573, 644), (592, 597), (601, 601), (609, 609)],    # damage application: node defence, the quotient, the subtraction
+               7: [(656, 706)],                                    # movement
+               8: [(708, 767), (291, 317), (321, 328)],            # capture, node / unit scores, status precedence (game_end)
+               9: [(37, 61), (133, 209)],                          # rewards (everglades_env.py:37-61), auto-reset = game_init (server.py:133-209)
+               10: [(382, 455), (457, 501), (158, 171)]}           # board_state, player_state, observation assembly (everglades_env.py:158-171)
+    o2, t2 = phases(two)
+    o4, t4 = phases(four)
+    assert o2 == list(range(1, 14)) and o4[-13:] == list(range(1, 14)), (o2, o4)
+    for k, want in anchors.items():
+        c2, c4 = cited(t2[k]), cited(t4[k])
+        for rng in want:
+            assert rng in c2, ("two-lane fragments, phase %d: no citation of lines %d-%d" % ((k,) + rng))
+            assert rng in c4, ("evg_step4.inc, phase %d: no citation of lines %d-%d" % ((k,) + rng))
