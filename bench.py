@@ -259,9 +259,9 @@ def compact_line(full):
         if not r:
             return None
         keep = ("bound", "bound_detail", "achieved", "peak", "unit", "frac", "achieved_kernel_events", "frac_kernel_events", "traffic", "kernel_ms",
-                "bytes_per_env_step", "bytes_source", "launch_form", "launches_timed",
-                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "hbm_proper_source", "algorithmic_bytes_per_env_step",
-                "traffic_over_algorithmic", "note")
+                "bytes_per_env_step", "bytes_source", "launches_timed",
+                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "algorithmic_bytes_per_env_step",
+                "traffic_over_algorithmic", "note")         # (hbm_proper_source: the *_cycled_pmc_traffic.json beside bytes_source's file)
         o = {k: _r(r[k], 5) for k in keep if k in r and r[k] is not None}
         for k in ("bytes_source", "hbm_proper_source"):        # (files under profiles/)
             if isinstance(o.get(k), str) and o[k].startswith("profiles/"):
@@ -272,9 +272,9 @@ def compact_line(full):
             o["traffic"] = None
         # (frac: bytes / ms_per_step of the region `value` comes from; *_kernel_events: bytes / HIP-event launch time -- `frac_is` of the full object)
         if r.get("bound_detail") == "fabric":
-            o["bound_detail_is"] = "L2<->InfinityCache/HBM requests; working set cache-resident"
+            o["bound_detail_is"] = "L2<->InfinityCache/HBM; working set cache-resident"
         if "survey_8d_frac" in o:
-            o["survey_8d_note"] = "4530 B model; >1: not applicable (state stays on chip)"
+            o["survey_8d_note"] = "4530 B model; >1: not applicable"
         if "note" in o:
             o["note"] = "working set cache-resident: latency/issue-bound, frac meaningless"
         bm = r.get("beyond_mall")
@@ -295,7 +295,7 @@ def compact_line(full):
                 o[sub] = {k: _r(l[sub][k], 4) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "epsilon") if k in l[sub]}
         if l.get("roofline"):
             # (bound, peak, unit and byte source: as in the main roofline object)
-            o["roofline"] = {k: _r(l["roofline"][k], 5) for k in ("achieved", "frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}
+            o["roofline"] = {k: _r(l["roofline"][k], 4) for k in ("frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}    # (achieved = frac x peak)
         return o
 
     c = full["config"]
@@ -309,7 +309,7 @@ def compact_line(full):
     out["config"] = {"workload": "%d concurrent DemoMap games per GPU, %s, persistent rollout form, auto-reset, obs %s [N,2,105]" % (
                          c["envs_per_gpu"], "random_actions vs random_actions drawn on device" if "random_actions" in c["workload"] else
                          "on-device Cycle_BRush_Turn25 vs SwarmAgent fused into the step kernel (BASELINE config 5)", obs_name),
-                     "window": "desynchronised: 150-turn pre-roll (phase hash(e) mod 150) + 150 settle",
+                     "window": "desynchronised: 150-turn pre-roll + 150 settle",
                      **{k: c[k] for k in ("envs_per_gpu", "total_envs", "turns_per_launch", "launch_form", "parallelism", "kernel_source_hash",
                                           "episodes_finished_rank0",
                                           "wins_p0_p1_tie_rank0", "gathered_wins_all_ranks") if k in c},
@@ -324,13 +324,14 @@ def compact_line(full):
         t = full["timing"]
         out["timing"] = {"repeats": t["repeats"], "reported": t["reported"], "min_ms_per_step": _r(t["min_ms_per_step"], 5),
                          "max_ms_per_step": _r(t["max_ms_per_step"], 5),
-                         "min_value": _r(t["min_value"], 5), "max_value": _r(t["max_value"], 5),
+                         "min_value": _r(t["min_value"], 4), "max_value": _r(t["max_value"], 4),
                          "clock_warmup_ms": _r(t.get("clock_warmup", {}).get("ms", 0.0), 3)}
         if "value_cold" not in full:     # (lines of round 5 carried it here)
             out["timing"]["cold_value"] = _r((t.get("clock_warmup", {}).get("cold_region") or {}).get("value"), 5)
     if "roofline_valu_issue" in full:
         v = full["roofline_valu_issue"]
-        out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "achieved", "peak", "frac", "valu_insts_per_wave_turn", "source")}
+        out["roofline_valu_issue"] = {k: _r(v[k], 5) for k in ("bound", "frac", "valu_insts_per_wave_turn", "source")}      # (achieved / peak: full object)
+        out["roofline_valu_issue"]["source"] = str(v["source"]).replace("profiles/", "")
     if "distributed" in full:
         d = dict(full["distributed"])
         d["collective"] = "pack kernel + ONE gather to rank 0 (= closing bracket); win-count self-check after the region"
@@ -362,7 +363,7 @@ def compact_line(full):
                                "sample": b["sample"].split(" (random vs random")[0] + ", random vs random + f64 obs; C port of the turn loop, OpenMP"}
         if "reference_python_env_steps_per_s" in b:      # the reference itself (pure Python, one core, build container): BASELINE.md section 2
             out["cpu_baseline"]["reference_python_env_steps_per_s"] = list(b["reference_python_env_steps_per_s"])
-            out["cpu_baseline"]["reference_python_source"] = "BASELINE.md s2, 1 core"
+            out["cpu_baseline"]["reference_python_is"] = "Python reference, 1 core (BASELINE.md s2)"
         if "same_games_as_gpu" in b:
             g = b["same_games_as_gpu"]
             out["cpu_baseline"]["same_games_as_gpu"] = {k: g[k] for k in ("envs", "turns", "equal", "cpu_wins_p0_p1_tie", "gpu_wins_p0_p1_tie")}

@@ -314,13 +314,13 @@ def test_bench_stdout_line_is_compact_and_complete():
     spec = importlib.util.spec_from_file_location("evg_bench2", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r05_d_bench_*.json")) if "compact" not in f)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r06_e_bench_*.json")) if "compact" not in f)
     assert len(files) >= 7
     for f in files:
         full = json.loads(open(f).read())
         line = json.dumps(bench.compact_line(full), separators=(",", ":"))
         # (a one-rank REHEARSAL carries the single-GPU legs and the distributed block at once; a real N > 1 line has no extra legs)
-        assert len(line) < (4100 if "rehearse_rccl" in f else 3600), (f, len(line))
+        assert len(line) < (4200 if "rehearse_rccl" in f else 3600), (f, len(line))
         c = json.loads(line)
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                   "config", "roofline"):
@@ -336,7 +336,7 @@ def test_bench_stdout_line_is_compact_and_complete():
         if "bound_detail" in c["roofline"]:          # round 6: `bound` is always the contract's value, the qualifier is a field of its own
             assert c["roofline"]["bound"] == "hbm" and c["roofline"]["bound_detail"] == "fabric" and "bound_detail_is" in c["roofline"]
         if full["config"]["envs_per_gpu"] == 65536 and full["config"]["workload"].startswith("65536 concurrent DemoMap games per GPU, random") and "float32" in full["config"]["workload"]:
-            assert 0.3 < c["roofline"]["hbm_proper_frac"] < 0.9 and "cycled" in c["roofline"]["hbm_proper_source"]
+            assert 0.3 < c["roofline"]["hbm_proper_frac"] < 0.9 and "cycled" in full["roofline"]["hbm_proper_source"]
             if "rehearse" not in f:                                   # (two gloo ranks share one GPU: that line's own fraction says nothing)
                 assert c["roofline"]["hbm_proper_frac"] < c["roofline"]["frac"] + 0.05      # leaving the cache does not make the kernel faster
         t = c["timing"]
@@ -344,6 +344,13 @@ def test_bench_stdout_line_is_compact_and_complete():
         if "cpu_baseline" in full:
             for k in ("value", "unit", "cores", "kind", "sample"):
                 assert k in c["cpu_baseline"]
+            assert c["cpu_baseline"]["reference_python_env_steps_per_s"] == [529, 554]       # the reference's own rate, as numbers, in the line
+        # round 6: the cold figure at top level beside `value`, one long region (`sustained`) beside the short ones, frac priced at ms_per_step
+        if full["n_gpus"] == 1 and "distributed" not in full:
+            assert c["value_cold"] and c["value_cold"] < c["value"] * 1.02
+            assert c["sustained"]["turns"] == 450 and 2.0 < c["sustained"]["region_ms"] < 12.0 and c["sustained"]["kernel_ms"] <= c["sustained"]["ms_per_step"]
+        assert c["roofline"]["frac"] <= c["roofline"]["frac_kernel_events"] * 1.001
+        assert abs(c["roofline"]["frac"] - c["roofline"]["bytes_per_env_step"] * full["config"]["envs_per_gpu"] / (c["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 2e-3 * c["roofline"]["frac"] or "distributed" in full
         for leg in ("one_launch_per_turn", "caller_actions_per_turn", "learner_vs_bot_per_turn"):
             if full["config"].get(leg):
                 assert c["config"][leg]["roofline"]["frac"] > 0 and c["config"][leg]["kernel_ms"] <= c["config"][leg]["ms_per_step"]
@@ -355,7 +362,7 @@ def test_bench_stdout_line_is_compact_and_complete():
             assert d["collective_us"] > 0 and d["gathered_wins_equal_sum_of_per_rank_counts"] is True and "expected" in d and 0 < d["step_share_of_region"] < 1
     # what a first multi-GPU line is read against: N x the committed one-rank RCCL rehearsal of the same shape, next to the one-GPU line of that shape
     exp = bench.expected_if_wire_free(8, 20)
-    assert exp and "r05_d_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
+    assert exp and "r06_e_bench_rehearse_rccl_1rank.json" in exp["from"] and abs(exp["value_if_wire_free"] / (8 * exp["per_gpu"]) - 1) < 1e-12
     # step launches / (step launches + collective path), one run
     assert 0.9 < exp["weak_scaling_efficiency_if_wire_free"] < 1.0 and exp["collective_us_1rank"] > 0
     assert bench.expected_if_wire_free(8, 12345) is None

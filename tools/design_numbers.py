@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Prints the "Numbers" list of DESIGN.md section 6 from the bench lines and counter summaries committed under profiles/ (one source per number).
-usage: python tools/design_numbers.py [name]      (default r05_d)"""
+usage: python tools/design_numbers.py [name]      (default r06_e)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAME = sys.argv[1] if len(sys.argv) > 1 else "r05_d"
+NAME = sys.argv[1] if len(sys.argv) > 1 else "r06_e"
 F = lambda n: json.load(open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (NAME, n))))
 fin, drv, c5, k4, i16, rc, gl = F("final"), F("driver_shape"), F("config5"), F("4096envs"), F("int16"), F("rehearse_rccl_1rank"), F("rehearse_gloo_2ranks_one_gpu")
 pm = json.load(open(os.path.join(ROOT, "profiles", NAME + "_pmc_traffic.json")))["forms"]
@@ -22,8 +22,9 @@ rows.append("* the driver's shape `--steps 20 --warmup 5` (median of %d regions)
 # the default command under rocprofv3, with the shader clock of every dispatch
 import re
 dr = open(os.path.join(ROOT, "profiles", NAME + "_default_run_kernel_stats.csv")).read().splitlines()
-m = re.search(r"median (\d+) us = ([\d.]+) us per turn.*roofline.kernel_ms = ([\d.]+)", dr[2])
-clk = [(float(a), float(b)) for a, b in re.findall(r"(\d+)@([\d.]+)", dr[4])]
+tl = next(l for l in dr if "timed 150-turn launches" in l)
+m = re.search(r"median (\d+) us = ([\d.]+) us per turn.*roofline.kernel_ms = ([\d.]+)", tl)
+clk = [(float(a), float(b)) for a, b in re.findall(r"(\d+)@([\d.]+)", next(l for l in dr if "GRBM_GUI_ACTIVE" in l))]
 slow, fast = max(clk), min(clk)
 rows.append("* the default command under rocprofv3 — median timed region %s µs per turn (the line of that run: %.2f); a 150-turn dispatch lasts %.2f ms at "
             "%.2f GHz and %.2f ms at %.2f GHz "
@@ -34,15 +35,22 @@ if os.path.exists(bx):
     mm = re.search(r"Spread of the value: ([\d.]+)-([\d.]+) G = ([\d.]+) %", open(bx).read())
     rows.append("* the driver's command in four separate gpurun calls (a fresh box each) — %.2f–%.2f G: %s %% [`%s_driver_shape_boxes.txt`]"
                 % (float(mm.group(1)), float(mm.group(2)), mm.group(3), NAME))
-cold = lambda d: d["timing"]["clock_warmup"]["cold_region"]["value"] / 1e9
-rows.append("* `timing.cold_value`, ONE K-step region timed before the clock warm-up and the W warm-up steps in the same run (what rounds 1–4 reported as "
+cold = lambda d: (d.get("value_cold") or d["timing"]["clock_warmup"]["cold_region"]["value"]) / 1e9
+rows.append("* `value_cold`, ONE K-step region timed before the clock warm-up and the W warm-up steps in the same run (what rounds 1–4 reported as "
             "the value) — driver shape %.2f G against "
             "%.2f G, default %.2f G against %.2f G [`%s_bench_driver_shape.json`, `%s_bench_final.json`]" % (cold(drv), G(drv), cold(fin), G(fin), NAME, NAME))
-cw = [l for l in open(os.path.join(ROOT, "profiles", NAME + "_clock_warmup_ab.txt")).read().splitlines() if not l.startswith("#")]
-gv = lambda l: float(re.search(r"([\d.]+) G env-steps/s", l).group(1))
-rows.append("* without the clock warm-up (`--clock-warmup-ms 0`, what earlier rounds measured), same box, back to back — driver shape %.2f G against %.2f G, "
-            "default %.2f G against %.2f G "
-            "[`%s_clock_warmup_ab.txt`]" % (gv(cw[0]), gv(cw[1]), gv(cw[2]), gv(cw[3]), NAME))
+if drv.get("sustained"):
+    sd, sf = drv["sustained"], fin["sustained"]
+    rows.append("* `sustained`, %d launches of 150 turns in ONE region (%.2f ms) right after the K-step regions of the same run — driver shape **%.2f G** (%.2f "
+                "µs/step, kernel %.2f µs/turn) beside its 20-step value of %.2f G; default run %.2f G (%.2f µs/step) [`%s_bench_driver_shape.json`, "
+                "`%s_bench_final.json`]" % (sd["launches"], sd["region_ms"], sd["value"] / 1e9, sd["ms_per_step"] * 1e3, sd["kernel_ms"] * 1e3, G(drv),
+                                            sf["value"] / 1e9, sf["ms_per_step"] * 1e3, NAME, NAME))
+cwf = os.path.join(ROOT, "profiles", NAME + "_clock_warmup_ab.txt")
+if os.path.exists(cwf):
+    cw = [l for l in open(cwf).read().splitlines() if not l.startswith("#")]
+    gv = lambda l: float(re.search(r"([\d.]+) G env-steps/s", l).group(1))
+    rows.append("* without the clock warm-up (`--clock-warmup-ms 0`, what earlier rounds measured), same box, back to back — driver shape %.2f G against %.2f "
+                "G, default %.2f G against %.2f G [`%s_clock_warmup_ab.txt`]" % (gv(cw[0]), gv(cw[1]), gv(cw[2]), gv(cw[3]), NAME))
 for k, nm, both in (("one_launch_per_turn", "one launch per turn, orders drawn in the kernel", "kernel alone"),
                     ("caller_actions_per_turn", "one launch per turn, orders from a caller tensor (the Gym consumer)", "both kernels of the turn"),
                     ("learner_vs_bot_per_turn", "learner seat vs on-device bot (`evg_step_vs_policy`, stand-in policy)", "both kernels of the turn")):
@@ -53,6 +61,10 @@ s = fin["config"]["learner_smart_actions_vs_bot_per_turn"]
 rows.append("* the same with `evg_smart_actions` as the learner's decode; + `evg_smart_state_compact` in front — %.2f G, %.1f µs stream per turn; %.2f G, "
             "%.1f µs [`%s_bench_final.json`]"
             % (s["env_steps_per_s"] / 1e9, s["kernel_ms"] * 1e3, s["with_features"]["env_steps_per_s"] / 1e9, s["with_features"]["kernel_ms"] * 1e3, NAME))
+if s.get("with_epsilon"):
+    rows.append("* the TRAINING turn: `evg_smart_get_action` (DQNAgent.get_action, epsilon %g: coin + get_random_actions on the device) instead of "
+                "`evg_smart_actions` — %.2f G, %.1f µs stream per turn [`%s_bench_final.json`]"
+                % (s["with_epsilon"]["epsilon"], s["with_epsilon"]["env_steps_per_s"] / 1e9, s["with_epsilon"]["kernel_ms"] * 1e3, NAME))
 p = fin["config"]["pipelined_halves_per_turn"]
 rows.append("* two half-batch handles free-running (`PipelinedVecEnv`) — %.2f G; %.1f µs wall, %.1f µs stream per turn of the whole batch (learner-seat "
             "turn: %.1f µs) [`%s_bench_final.json`]"
@@ -63,13 +75,16 @@ rows.append("* persistent without observations / with float64 observations / int
             % (n["env_steps_per_s"] / 1e9, n["ms_per_step"] * 1e3, o["env_steps_per_s"] / 1e9, o["ms_per_step"] * 1e3, G(i16), i16["ms_per_step"] * 1e3, NAME,
                NAME))
 r = fin["roofline"]
-rows.append("* roofline (bound `fabric`): bytes per env-step, rate, fraction of 8 TB/s — persistent %.0f B → %.2f TB/s = **%.2f** at the live kernel time "
-            "(%.2f at rocprofv3's %.2f µs); one launch per turn %.0f B → **%.2f**; "
-            "caller orders %.0f B → **%.2f**; learner seat %.0f B → **%.2f**; driver shape **%.2f** [`%s_pmc_traffic.json`, bench lines]"
-            % (r["bytes_per_env_step"], r["achieved"] / 1e3, r["frac"], pm["persistent"]["frac_of_8TBps"], pm["persistent"]["kernel_us_per_turn"],
+rows.append("* roofline (`bound` hbm, `bound_detail` fabric): bytes per env-step, rate, fraction of 8 TB/s — persistent %.0f B → %.2f TB/s = **%.2f** at "
+            "the `ms_per_step` of the region `value` comes from (`frac_kernel_events` %.2f at the launches' own HIP-event time; "
+            "%.2f at rocprofv3's %.2f µs); one launch per turn %.0f B → **%.2f**; "
+            "caller orders %.0f B → **%.2f**; learner seat %.0f B → **%.2f**; driver shape **%.2f** (`frac_kernel_events` %.2f) [`%s_pmc_traffic.json`, bench lines]"
+            % (r["bytes_per_env_step"], r["achieved"] / 1e3, r["frac"], r.get("frac_kernel_events", r["frac"]), pm["persistent"]["frac_of_8TBps"],
+               pm["persistent"]["kernel_us_per_turn"],
                pm["one_launch_per_turn"]["bytes_per_env_step"], pm["one_launch_per_turn"]["frac_of_8TBps"],
                pm["caller_actions_per_turn"]["bytes_per_env_step"], pm["caller_actions_per_turn"]["frac_of_8TBps"],
-               pm["learner_vs_bot_per_turn"]["bytes_per_env_step"], pm["learner_vs_bot_per_turn"]["frac_of_8TBps"], drv["roofline"]["frac"], NAME))
+               pm["learner_vs_bot_per_turn"]["bytes_per_env_step"], pm["learner_vs_bot_per_turn"]["frac_of_8TBps"], drv["roofline"]["frac"],
+               drv["roofline"].get("frac_kernel_events", drv["roofline"]["frac"]), NAME))
 if r.get("algorithmic_bytes_per_env_step"):
     rows.append("* algorithmic bytes of this design / counter bytes — %.0f B (971 B of outputs + 2 × %.0f B of health rows) / %.0f B: "
                 "`traffic_over_algorithmic` %.2f [`%s_bench_final.json`]"

@@ -23,7 +23,7 @@ durs = [d for _, d in rows]
 line = json.loads([l for l in open("$OUT/bench.json") if l.startswith("{")][-1])
 R, K = int(line["timing"]["repeats"]), int(line["steps"])
 L = K // 150                                                        # launches per region
-S = int((line.get("sustained") or {}).get("launches", 0))           # the `sustained` leg: S more 150-turn launches in one region, right after the timed ones
+S = int((line.get("sustained") or {}).get("launches", 0))           # the sustained leg: S more 150-turn launches in one region, right after the timed ones
 sust = durs[len(durs) - S:] if S else []
 timed = durs[len(durs) - S - R * L:len(durs) - S]
 regions = [sum(timed[i * L:(i + 1) * L]) for i in range(R)]
@@ -36,7 +36,7 @@ for r in sorted((r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"
 stats = open(glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]).read().splitlines()
 out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-extra-legs      (kernel_source_hash %s)"' % line["config"]["kernel_source_hash"],
        '"# persistent step-kernel dispatches of the run, in order (us): %s"' % " ".join("%.0f" % (d / 1e3) for d in durs),
-       '"# the LAST %d dispatches are the `sustained` leg (one region): %s us; the line says sustained.kernel_ms = %s, sustained.ms_per_step = %s"'
+       '"# the LAST %d dispatches are the sustained leg (one region): %s us; the line says sustained.kernel_ms = %s, sustained.ms_per_step = %s"'
        % (S, " ".join("%.0f" % (x / 1e3) for x in sust), (line.get("sustained") or {}).get("kernel_ms"), (line.get("sustained") or {}).get("ms_per_step")),
        '"# the %d before them are the timed 150-turn launches: %d regions of %d launches = %d turns each (bench.py reports the median region).  Region sums (us): %s; median %.0f us = '
        '%.2f us per turn.  The line of the same run: roofline.kernel_ms = %.5f, ms_per_step = %.5f (regions min %.5f, max %.5f)"'

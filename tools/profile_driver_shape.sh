@@ -18,13 +18,13 @@ pers = [(i, n, d) for i, n, d in rows if "evg_step_kernel<float, 64, true, false
 line = json.loads([l for l in open("$OUT/bench.json") if l.startswith("{")][-1])
 stats = open(glob.glob("$OUT/stats/*/*_kernel_stats.csv")[0]).read().splitlines()
 R = int((line.get("timing") or {}).get("repeats", 1))
-S = int((line.get("sustained") or {}).get("launches", 0))  # the `sustained` leg: S 150-turn launches in ONE region, right after the timed regions
+S = int((line.get("sustained") or {}).get("launches", 0))  # the sustained leg: S 150-turn launches in ONE region, right after the timed regions
 sust = [d for _, _, d in pers[len(pers) - S:]] if S else []
 timed = [d for _, _, d in pers[len(pers) - S - R:len(pers) - S]]    # the R timed regions are the R 20-turn dispatches before them (bench.py reports the median region)
 med = sorted(timed)[(R - 1) // 2]
 out = ['"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs"',
        '"# persistent step-kernel dispatches of the run, in order (ns): %s"' % " ".join(str(d) for _, _, d in pers),
-       '"# the LAST %d are the launches of the `sustained` leg (one region of %d x 150 turns): %s ns = %.2f us per turn; the line of the same run says sustained.kernel_ms = %s, sustained.ms_per_step = %s (region %s ms)"'
+       '"# the LAST %d are the launches of the sustained leg (one region of %d x 150 turns): %s ns = %.2f us per turn; the line of the same run says sustained.kernel_ms = %s, sustained.ms_per_step = %s (region %s ms)"'
        % (S, S, " ".join(str(d) for d in sust), (sum(sust) / (150.0 * S) / 1e3) if S else 0.0, (line.get("sustained") or {}).get("kernel_ms"), (line.get("sustained") or {}).get("ms_per_step"), (line.get("sustained") or {}).get("region_ms")),
        '"# the %d before them are the timed 20-turn launches (bench.py times the exact 20-step region %d times and reports the median region): %s ns; median %d ns = %.2f us per turn; '
        'the line of the same run says roofline.kernel_ms = %.5f (x 20 turns = %.1f us between the two stream events of its median region), ms_per_step = %.5f (min %.5f, max %.5f)"'
