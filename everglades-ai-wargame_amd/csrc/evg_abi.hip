@@ -263,7 +263,12 @@ void evg_default_tables(evg_tables* t) {
 // dfs_attack.py ignores its observation, so its orders are a function of the call count alone.  Simulate the bot
 // (depth-first sweep over the map with two attack groups, delays in between, and the rows that persist in the mutable
 // default argument of act_dfs_attack) until its whole state repeats; the kernel then indexes the table.
-static void build_dfs_table(const evg_tables& t, DevTables* D) {
+// The scripted bots of agents/State_Machine/ do not read the map file: every one of them carries DemoMap's NODE_CONNECTIONS as a module constant
+// (swarm_agent.py:15-27, dfs_attack.py:11-23, ...), so on ANOTHER map (EvergladesEnv.reset(map_file=)) they still route by DemoMap -- many of their orders are
+// then rejected by the server, which is the reference's behaviour (pinned by tests/golden/custom_agents.npz).  Bit m of entry n: m is in NODE_CONNECTIONS[n].
+static const uint16_t kBotConnections[12] = {0, 0x014, 0x02A, 0x0F4, 0x08A, 0x30C, 0x208, 0x618, 0xA20, 0x5E0, 0xA80, 0x500};
+
+static void build_dfs_table(DevTables* D) {
     struct St { int first, group_index, delay_turns, delay, prev; uint32_t visited; std::vector<int> stack; uint64_t persist;
                 bool operator==(const St& o) const { return first == o.first && group_index == o.group_index && delay_turns == o.delay_turns &&
                     delay == o.delay && prev == o.prev && visited == o.visited && stack == o.stack && persist == o.persist; } };
@@ -293,7 +298,7 @@ static void build_dfs_table(const evg_tables& t, DevTables* D) {
                 s.group_index += 1;
                 s.stack.pop_back();
                 s.visited |= 1u << (n - 1);
-                for (int m = 1; m <= NN; ++m) if (t.node_dist[n][m] > 0 && !((s.visited >> (m - 1)) & 1u)) s.stack.push_back(m);
+                for (int m = 1; m <= NN; ++m) if (((kBotConnections[n] >> m) & 1u) && !((s.visited >> (m - 1)) & 1u)) s.stack.push_back(m);   // dfs_attack.py:131
             } else {
                 s.group_index = 0; s.delay_turns = 5; s.delay = 0; s.stack.assign(1, 1); s.visited = 0u;
             }
@@ -424,10 +429,10 @@ static int build_dev_tables(const evg_config* cfg, DevTables* D) {
         D->tar_to_1 |= (uint64_t)(to1[c - 1] < 0 ? 15 : to1[c - 1]) << (4 * c);
         D->tar_to_11 |= (uint64_t)(to11[c - 1] < 0 ? 15 : to11[c - 1]) << (4 * c);
     }
-    build_dfs_table(t, D);
+    build_dfs_table(D);
     for (int n = 1; n <= NN; ++n) {
         int best = 0;
-        for (int m = 1; m <= NN; ++m) if (t.node_dist[n][m] > 0) best = m;
+        for (int m = 1; m <= NN; ++m) if ((kBotConnections[n] >> m) & 1u) best = m;     // max(NODE_CONNECTIONS[n]) of swarm_agent.py:97: the bot's own constant
         D->maxnbr_nib |= (uint64_t)best << (4 * n);
         for (int m = 1; m <= NN; ++m) if (t.node_dist[n][m] > 0) D->nbr_mask[n] |= 1u << m;
     }

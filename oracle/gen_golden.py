@@ -952,6 +952,39 @@ def gen_custom_fixtures(R, only=None):
     R.cfg = saved_cfg
 
 
+def gen_custom_agent_fixtures(R):
+    """tests/golden/custom_agents.npz: the reference's own scripted agent classes playing on the NON-default maps of oracle/custom_configs.py.  None of them reads
+    the map file -- each carries DemoMap's NODE_CONNECTIONS (and TAR_NODE) as a module constant -- so on varA / varB they still route by DemoMap and many of their
+    orders are rejected by the server (server.py:245-252): the reference's behaviour, which the on-device bots must share.  Three episodes per pairing, agent
+    objects alive across them (evaluate.py:85-93)."""
+    import json
+    import tempfile
+    import custom_configs as cc
+    demo_map = json.load(open(os.path.join(REF, "config", "DemoMap.json")))
+    demo_units = json.load(open(os.path.join(REF, "config", "UnitDefinitions.json")))
+    saved_cfg = dict(R.cfg)
+    tmp = tempfile.mkdtemp(prefix="evg_custom_agents_")
+    B = dict(swarm=("swarm_agent.py", "SwarmAgent"), cyc25=("cycle_rush_turn25.py", "Cycle_BRush_Turn25"), dfs=("dfs_attack.py", "dfs_attack"),
+             ctn=("cycle_target_node.py", "Cycle_Target_Node"), ctn1=("cycle_target_node1.py", "cycle_targetedNode1"), bull=("bull_rush.py", "bull_rush"),
+             brv1=("base_rush_v1.py", "base_rushV1"), rnd=("random_actions.py", "random_actions"))
+    plans = [("varA", ("swarm", "cyc25"), 71, 3), ("varA", ("dfs", "swarm"), 72, 4), ("varA", ("ctn", "dfs"), 73, 5), ("varA", ("rnd", "ctn1"), 74, 6),
+             ("varB", ("cyc25", "swarm"), 75, 7), ("varB", ("swarm", "dfs"), 76, 8), ("varB", ("bull", "brv1"), 77, 9), ("varB", ("dfs", "rnd"), 78, 10)]
+    games = []
+    for name, (a, b), seed, env_id in plans:
+        mobj, uobj, _ = cc.variant_objects(name, demo_map, demo_units)
+        mpath, upath = os.path.join(tmp, name + "_map.json"), os.path.join(tmp, name + "_units.json")
+        open(mpath, "w").write(cc.json_text(mobj)), open(upath, "w").write(cc.json_text(uobj))
+        R.cfg = dict(saved_cfg, map_file=mpath, unit_file=upath)
+        games.append(play_agents(R, (B[a], B[b]), seed, env_id, 3))
+    R.cfg = saved_cfg
+    d = dict(variant=np.array([p[0] for p in plans]), policy=np.array([[AGENT_POLICY[B[x][1]] for x in p[1]] for p in plans], np.int32),
+             seed=np.array([p[2] for p in plans], np.uint64), env_id=np.array([p[3] for p in plans], np.uint32))
+    for k in games[0]:
+        d[k] = np.stack([g[k] for g in games])
+    np.savez_compressed(os.path.join(OUT, "custom_agents.npz"), **d)
+    print("custom agents:", d["length"].tolist(), d["status"].tolist(), flush=True)
+
+
 # ----------------------------------------------------------------------------------------------
 def kat_script():
     """deterministic no-combat trajectory."""
@@ -1004,6 +1037,9 @@ def main():
     if os.environ.get("EVG_GOLDEN_ONLY") == "config1":
         gen_config1_fixture(R)
         return
+    if os.environ.get("EVG_GOLDEN_ONLY") == "custom_agents":
+        gen_custom_agent_fixtures(R)
+        return
     if (os.environ.get("EVG_GOLDEN_ONLY") or "").startswith("custom"):      # custom | custom:varA
         gen_custom_fixtures(R, only=(os.environ["EVG_GOLDEN_ONLY"].split(":") + [None])[1])
         return
@@ -1054,6 +1090,7 @@ def main():
     gen_stock_mt_fixture(R)
     gen_config1_fixture(R)
     gen_custom_fixtures(R)
+    gen_custom_agent_fixtures(R)
 
     # 4. bulk random-vs-random: outcomes + per-turn checksums only
     B = 120

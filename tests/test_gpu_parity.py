@@ -373,6 +373,40 @@ def test_scripted_agents_golden_through_abi(evg):
         env.close()
 
 
+def test_scripted_agents_on_non_default_maps_through_abi(evg, tmp_path):
+    """tests/golden/custom_agents.npz through the C-ABI: the reference's agent classes on the maps of custom_varA / custom_varB (they keep routing by their
+    own DemoMap constants, whatever map file the env was reset with) -- the on-device bots emit the same orders from the observation tensor
+    (evg_scripted_actions), and from the on-chip state inside the step kernel (evg_step_vs_policy on both seats), and the env plays the same games."""
+    d = load_golden("custom_agents.npz")
+    G, E = d["length"].shape
+    for g in range(G):
+        vname = "custom_%s.npz" % str(d["variant"][g])
+        v = load_golden(vname)
+        tables = evg.tables_from_json(p1_node_map=v["p1_node_map"].tolist(), **_custom_fixture_files(v, vname, tmp_path))
+        pol = [int(x) for x in d["policy"][g]]
+        for form in ("scripted_actions", "step_vs seat 0", "step_vs seat 1"):
+            env = evg.EvergladesVecEnv(1, seed=int(d["seed"][g]), env_id_base=int(d["env_id"][g]), obs_dtype="float64", auto_reset=False, tables=tables)
+            for ep in range(E):
+                obs = env.reset()
+                for t in range(int(d["length"][g, ep])):
+                    want = d["actions"][g, ep, t]
+                    if form == "scripted_actions":
+                        assert np.array_equal(_np(obs)[0], d["obs"][g, ep, t].astype(np.float64)), (g, ep, t)
+                        env.scripted_actions(pol[0], 0)
+                        a = env.scripted_actions(pol[1], 1)
+                        assert np.array_equal(_np(a)[0], want), ("orders", g, ep, t)
+                        obs, rew, done, info = env.step(a)
+                    else:
+                        seat = int(form[-1])                     # the recorded rows of `seat` are the caller's; the other seat's bot runs inside the kernel
+                        import torch
+                        rows = torch.as_tensor(want[seat].astype(np.int32), device=env.device).reshape(1, 7, 2).contiguous()
+                        sobs, rew, done, info = env.step_vs(pol[1 - seat], rows, seat=seat)
+                        assert np.array_equal(_np(sobs)[0], d["obs"][g, ep, t + 1, seat].astype(np.float64)), (form, g, ep, t)
+                assert int(done[0]) == 1 and int(info["status"][0]) == d["status"][g, ep], (form, g, ep)
+                assert np.array_equal(_np(info["scores"])[0], d["scores"][g, ep]), (form, g, ep)
+            env.close()
+
+
 def test_learner_seat_turn_replays_the_references_agent_classes(evg):
     """evg_step_vs_policy pinned by the REFERENCE, not by the oracle: in every pairing of tests/golden/agents_scripted.npz (the reference's own agent
     classes on its own server, three consecutive episodes each) one seat's RECORDED orders are handed in as the caller's rows and the other seat's bot is
