@@ -290,9 +290,9 @@ def compact_line(full):
         if not l:
             return None
         o = {k: _r(l[k], 4) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "turns_per_launch", "parts") if k in l}
-        for sub in ("learner_vs_bot", "with_features", "with_epsilon"):
+        for sub in ("learner_vs_bot", "with_features", "with_features_fused", "with_epsilon"):
             if l.get(sub):
-                o[sub] = {k: _r(l[sub][k], 4) for k in ("env_steps_per_s", "ms_per_step", "kernel_ms", "epsilon") if k in l[sub]}
+                o[sub] = {k: _r(l[sub][k], 4) for k in ("env_steps_per_s", "kernel_ms", "epsilon") if k in l[sub]}     # (ms_per_step: full object)
         if l.get("roofline"):
             # (bound, peak, unit and byte source: as in the main roofline object)
             o["roofline"] = {k: _r(l["roofline"][k], 4) for k in ("frac", "bytes_per_env_step") if l["roofline"].get(k) is not None}    # (achieved = frac x peak)
@@ -854,17 +854,20 @@ class Run(object):
         def turns(features, epsilon):
             def run(n):
                 for t_ in range(n):
-                    if features:
+                    if features == "kernel":
                         env.smart_state_compact(-1, sobs, sh, sw)
                     rows = env.smart_actions(qs[t_ & 7], obs=sobs) if epsilon is None else env.smart_get_action(qs[t_ & 7], epsilon, seat=0, obs=sobs)
-                    env.step_vs(args.opponent, rows, seat=0)                 # (step_vs writes the next observation into sobs)
+                    # (step_vs writes the next observation into sobs -- and, fused, the next features into sh / sw: evg_step_vs_policy_smart)
+                    env.step_vs(args.opponent, rows, seat=0, features=(sh, sw) if features == "fused" else None)
             return run
-        leg = self.timed_python_loop(turns(False, None), 2)
-        leg["with_features"] = self.timed_python_loop(turns(True, None), 3)
-        leg["with_epsilon"] = dict(self.timed_python_loop(turns(False, args.epsilon), 2), epsilon=args.epsilon)
+        leg = self.timed_python_loop(turns(None, None), 2)
+        leg["with_features"] = self.timed_python_loop(turns("kernel", None), 3)
+        leg["with_features_fused"] = self.timed_python_loop(turns("fused", None), 2)
+        leg["with_epsilon"] = dict(self.timed_python_loop(turns(None, args.epsilon), 2), epsilon=args.epsilon)
         leg["path"] = ("per turn, from a Python loop over the C-ABI: evg_smart_actions(Q [N,12,5] f32, one-seat obs) -> [N,7,2] orders (DQNAgent.get_best_actions "
                        "on the device) -> evg_step_vs_policy(opponent `%s` inside the step kernel); with_features: evg_smart_state_compact in front (the network's "
-                       "input); with_epsilon: evg_smart_get_action instead (DQNAgent.get_action, epsilon %g: coin + get_random_actions on the device)"
+                       "input); with_features_fused: the features written by the step launch itself (evg_step_vs_policy_smart); with_epsilon: "
+                       "evg_smart_get_action instead (DQNAgent.get_action, epsilon %g: coin + get_random_actions on the device)"
                        % (args.opponent, args.epsilon))
         return leg
 

@@ -26,7 +26,8 @@ POLICY_NAMES = ["random", "cycle_rush_turn25", "cycle_rush_turn50", "swarm", "al
                 "random_actions_delay", "same_commands"]      # index = EVG_POLICY_* of include/evg.h (agents/State_Machine/<name>.py)
 POLICY_ALIASES = {"random_actions": 0, "random_actions_2": 0, "swarm_agent": 3, "same_commands_2": 14}
 
-EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_observe_seat",
+EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_step", "evg_observe", "evg_step_vs_policy", "evg_step_vs_policy_smart",
+           "evg_observe_seat",
            "evg_random_actions_seat", "evg_smart_state_seat", "evg_smart_state_compact", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war",
            "evg_sightings", "evg_smart_state", "evg_smart_actions", "evg_smart_get_action", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies",
            "evg_scripted_actions", "evg_scripted_reset",
@@ -141,6 +142,7 @@ def load(path=None):
     L.evg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.evg_observe.argtypes = [vp, vp, vp]
     L.evg_step_vs_policy.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.evg_step_vs_policy_smart.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.evg_observe_seat.argtypes = [vp, C.c_int, vp, vp]
     L.evg_random_actions_seat.argtypes = [vp, C.c_int, vp, vp]
     L.evg_smart_state_seat.argtypes = [vp, vp, vp, vp]

@@ -169,7 +169,8 @@ static int check_fault(evg_handle* h, uint32_t* word_out = nullptr) {
 static bool same_launch(const StepIO& a, const StepIO& b) {
     bool same = a.actions == b.actions && a.obs == b.obs && a.reward == b.reward && a.done == b.done && a.winner == b.winner && a.scores == b.scores &&
                 a.status == b.status && a.observe_only == b.observe_only && a.gen_actions == b.gen_actions && a.policy0 == b.policy0 &&
-                a.policy1 == b.policy1 && a.actions_out == b.actions_out && a.turns == b.turns && a.seat == b.seat && a.actions_both == b.actions_both;
+                a.policy1 == b.policy1 && a.actions_out == b.actions_out && a.turns == b.turns && a.seat == b.seat && a.actions_both == b.actions_both &&
+                a.feat_shared == b.feat_shared && a.feat_swarm == b.feat_swarm;
 #ifdef EVG_DIAG
     same = same && a.lanes_per_wave == b.lanes_per_wave && a.ablate == b.ablate && a.stamps == b.stamps;
 #endif
@@ -646,19 +647,36 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     return EVG_OK;
 }
 
-int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out, float* reward_out,
-                       uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream) {
+static int step_vs_policy_impl(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out,
+                               float* shared_out, float* swarm_out, float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out,
+                               uint8_t* status_out, void* stream) {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !obs_seat_out || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, obs_seat_out, reward_out and done_out are required");
     if (seat < 0 || seat > 1 || opponent_policy < 0 || opponent_policy >= EVG_POLICY_COUNT) return fail(EVG_ERR_INVALID, "seat / opponent_policy out of range");
     EVG_NEED_ALIGNED16(obs_seat_out); EVG_NEED_ALIGNED16(actions); EVG_NEED_ALIGNED8(reward_out); EVG_NEED_ALIGNED8(scores_out);
+    EVG_NEED_ALIGNED8(shared_out); EVG_NEED_ALIGNED16(swarm_out);
     if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_step_vs_policy: keyed-Philox handles only (the stock-entropy mode has no fused bots)");
     EVG_ON_DEVICE(h);
     StepIO io = make_io(h, actions, obs_seat_out, reward_out, done_out, winner_out, scores_out, status_out, 0, 2, opponent_policy, opponent_policy, nullptr);
     io.seat = seat; io.actions_both = actions_both_seats ? 1 : 0;
+    io.feat_shared = shared_out; io.feat_swarm = swarm_out;
     const int rc = launch_step_seat(h->S, io, h->cfg.obs_dtype, h->caps, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
+}
+
+int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out, float* reward_out,
+                       uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream) {
+    return step_vs_policy_impl(h, seat, actions, actions_both_seats, opponent_policy, obs_seat_out, nullptr, nullptr, reward_out, done_out, winner_out, scores_out,
+                               status_out, stream);
+}
+
+int evg_step_vs_policy_smart(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out,
+                             float* shared_out, float* swarm_out, float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out,
+                             uint8_t* status_out, void* stream) {
+    if (!shared_out || !swarm_out) return fail(EVG_ERR_INVALID, "evg_step_vs_policy_smart: shared_out and swarm_out are required (evg_step_vs_policy is the form without)");
+    return step_vs_policy_impl(h, seat, actions, actions_both_seats, opponent_policy, obs_seat_out, shared_out, swarm_out, reward_out, done_out, winner_out,
+                               scores_out, status_out, stream);
 }
 
 int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream) {

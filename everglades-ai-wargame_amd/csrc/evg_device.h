@@ -140,6 +140,8 @@ struct StepIO {
                                  // or rows [:, seat] of [N][2][7][2] when actions_both != 0), the other seat's from policy0 / policy1 (gen_actions == 2),
                                  // and obs is [N][105]
     int32_t   actions_both;
+    float*    feat_shared;       // SEAT instantiation only (evg_step_vs_policy_smart): non-NULL = also write the Smart_State features of the caller's seat, compact
+    float*    feat_swarm;        // form -- shared [N][34], swarm [N][12][13] (evg_smart_state_compact's outputs) -- straight from the observation image in LDS
     int32_t   nsets;             // > 0: CHUNKED persistent launch of the two-lane kernel (batches beyond what the device holds at once): workgroup u
                                  // plays chunk u / nsets (chunk_turns consecutive turns, the last one what is left of `turns`) of env set u % nsets
     int32_t   chunk_turns;

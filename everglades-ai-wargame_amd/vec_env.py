@@ -204,13 +204,15 @@ class EvergladesVecEnv(object):
             self._p["obs_seat"] = C.c_void_p(self._obs_seat.data_ptr())
         return self._obs_seat
 
-    def step_vs(self, policy, actions, seat=0, out=None):
+    def step_vs(self, policy, actions, seat=0, out=None, features=None):
         """One turn of the loop the reference's training and evaluation scripts run (evaluate.py:143-152;
         agents/Smart_State/training_scripts/dqn_smart_state_training.py:114-122): the caller plays `seat` with `actions` -- int32
         [N, 7, 2], or a [N, 2, 7, 2] tensor whose rows [:, seat] are used --, the on-device scripted bot `policy` (a name from
         _lib.POLICY_NAMES or an EVG_POLICY_* id) plays the other seat, evaluated INSIDE the step kernel from the on-chip state
         (evg_step_vs_policy: one launch, no opponent observations or orders through HBM).  Returns (obs_seat [N, 105] -- the caller's
-        seat only --, reward [N, 2], done [N], info) like step(); bit-identical to scripted_actions(policy, 1 - seat) + step()."""
+        seat only --, reward [N, 2], done [N], info) like step(); bit-identical to scripted_actions(policy, 1 - seat) + step().
+        features=(shared [N, 34], swarm [N, 12, 13]) float32 tensors: the launch ALSO writes the Smart_State features of the new observation into them
+        (evg_step_vs_policy_smart: what smart_state_compact(-1, obs_seat, shared, swarm) would compute afterwards, without that kernel)."""
         torch = _torch()
         pid = self.POLICIES[policy] if isinstance(policy, str) else int(policy)
         a = actions
@@ -225,8 +227,16 @@ class EvergladesVecEnv(object):
             raise ValueError("actions must have shape [N, 7, 2] (the caller's seat) or [N, 2, 7, 2], got %s" % (tuple(a.shape),))
         obs = self._seat_buffers() if out is None else self._user(out, (self.num_envs, _lib.OBS_LEN), self.obs_dtype, "out")
         p = self._p
-        rc = self.L.evg_step_vs_policy(self._h, int(seat), C.c_void_p(a.data_ptr()), both, pid, C.c_void_p(obs.data_ptr()), p["reward"], p["done"], p["winner"],
-                                       p["scores"], p["status"], self._stream())
+        if features is not None:
+            shared, swarm = features
+            self._user(shared, (self.num_envs, 34), torch.float32, "features[0] (shared)")
+            self._user(swarm, (self.num_envs, _lib.NUM_GROUPS, 13), torch.float32, "features[1] (swarm)")
+            rc = self.L.evg_step_vs_policy_smart(self._h, int(seat), C.c_void_p(a.data_ptr()), both, pid, C.c_void_p(obs.data_ptr()),
+                                                 C.c_void_p(shared.data_ptr()), C.c_void_p(swarm.data_ptr()), p["reward"], p["done"], p["winner"], p["scores"],
+                                                 p["status"], self._stream())
+        else:
+            rc = self.L.evg_step_vs_policy(self._h, int(seat), C.c_void_p(a.data_ptr()), both, pid, C.c_void_p(obs.data_ptr()), p["reward"], p["done"],
+                                           p["winner"], p["scores"], p["status"], self._stream())
         if rc:
             self._check(rc)
         return obs, self.reward, self.done, self._info

@@ -37,7 +37,8 @@ extern "C" {
 #endif
 
 #define EVG_ABI_VERSION 6
-/* 6: evg_smart_get_action (DQNAgent.get_action with epsilon > 0); reward / score buffers need 8-byte alignment only (5 asked 16 of every buffer)
+/* 6: evg_smart_get_action (DQNAgent.get_action with epsilon > 0), evg_step_vs_policy_smart (the learner-seat turn that also writes the Smart_State
+ *    features); reward / score buffers need 8-byte alignment only (5 asked 16 of every buffer)
  * 5: evg_smart_actions; evg_comm_unique_id / evg_comm_init / evg_gather_returns / evg_comm_destroy + EVG_ERR_COMM; every device buffer must be
  *    16-byte aligned (checked)
  * 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat, evg_smart_state_compact,
@@ -191,6 +192,14 @@ EVG_API int evg_observe(evg_handle* h, void* obs_out, void* stream);
  * section 6); what is saved is the bot's own kernel (7-9 us and 55 MB of observations read back) and the traffic listed above. */
 EVG_API int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out,
                                float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream);
+/* The same turn for a Smart_State learner (agents/Smart_State/DQNAgent.py): besides the seat's observation the launch also writes the agent's network INPUT
+ * of the next turn -- the features of DQNAgent.create_swarm_obs (:268-300) in the compact form of evg_smart_state_compact: shared_out device float [N][34]
+ * (8-byte aligned), swarm_out device float [N][12][13] (16-byte aligned) -- computed from the observation image while it is still on chip.  Value for value
+ * what evg_smart_state_compact(h, -1, obs_seat_out, shared_out, swarm_out) would write after this call, without that kernel (23 us at 65 536 envs) and
+ * without reading the row back.  The first features of a loop (after evg_reset) come from evg_observe_seat + evg_smart_state_compact. */
+EVG_API int evg_step_vs_policy_smart(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out,
+                                     float* shared_out, float* swarm_out, float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out,
+                                     uint8_t* status_out, void* stream);
 /* evg_observe for one seat: obs_seat_out device [N][105] (after evg_reset / evg_set_state, to start a evg_step_vs_policy loop). */
 EVG_API int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream);
 

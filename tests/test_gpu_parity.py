@@ -638,6 +638,42 @@ def test_smart_state_features_match_reference_fixture(evg):
         env.close()
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64", "int16"])
+def test_learner_seat_turn_with_fused_smart_state_features(evg, oracle_mod, dtype):
+    """evg_step_vs_policy_smart: the learner-seat turn that also writes the Smart_State agent's next network input (DQNAgent.create_swarm_obs,
+    agents/Smart_State/DQNAgent.py:268-300, compact form) from the observation image while it is on chip.  Over 40 turns with auto-resets, both seats, a ragged
+    batch and every observation dtype: (1) the game is the one evg_step_vs_policy plays (same observation, rewards, state); (2) shared / swarm equal what
+    evg_smart_state_compact computes from the written observation, bit for bit; (3) expanded, they equal float32(the oracle's float64 features)."""
+    import torch
+    N = 2 * 8192 + 77
+    for seat in (0, 1):
+        a = evg.EvergladesVecEnv(N, seed=21, auto_reset=True, obs_dtype=dtype)
+        b = evg.EvergladesVecEnv(N, seed=21, auto_reset=True, obs_dtype=dtype)
+        a.reset(); b.reset()
+        a.rollout_policies(85, "cycle_rush_turn25", "swarm", fused=True, turns_per_launch=85)       # mid-game, some envs about to end: auto-resets follow
+        b.rollout_policies(85, "cycle_rush_turn25", "swarm", fused=True, turns_per_launch=85)
+        shared = torch.full((N, 34), -7.0, device=a.device)
+        swarm = torch.full((N, 12, 13), -7.0, device=a.device)
+        bot = "swarm" if seat == 0 else "cycle_rush_turn25"
+        for t in range(40):
+            rows = a.random_actions_seat(seat)
+            rows_b = b.random_actions_seat(seat)
+            sobs, rew, done, info = a.step_vs(bot, rows, seat=seat, features=(shared, swarm))
+            sobs_b, rew_b, done_b, info_b = b.step_vs(bot, rows_b, seat=seat)
+            assert torch.equal(sobs, sobs_b) and torch.equal(rew, rew_b) and torch.equal(done, done_b) and torch.equal(info["scores"], info_b["scores"]), (seat, t)
+            want_sh, want_sw = b.smart_state_compact(-1, sobs_b)
+            assert torch.equal(shared, want_sh), (seat, t, "shared")
+            assert torch.equal(swarm, want_sw), (seat, t, "swarm")
+            if t % 13 == 0:
+                want = oracle_mod.smart_state(_np(sobs).astype(np.float64)).astype(np.float32)
+                assert np.array_equal(_np(evg.EvergladesVecEnv.expand_smart_state(shared, swarm)), want), (seat, t, "oracle")
+        assert int(a.episode_stats()["totals"][0]) > 0                                                  # episodes did end and restart inside the loop
+        check_state(a, b.get_state(), "fused features")
+        with pytest.raises(ValueError):
+            a.step_vs(bot, rows, seat=seat, features=(shared[:-1], swarm))
+        a.close(); b.close()
+
+
 def test_smart_state_multi_pass_ragged_vs_oracle(evg, oracle_mod):
     """The feature kernel at a size that needs several passes of its resident grid and is not a multiple of its 4 envs per
     block, on mid-game observations of both seats: equal to float32(oracle float64)."""

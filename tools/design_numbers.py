@@ -61,6 +61,9 @@ s = fin["config"]["learner_smart_actions_vs_bot_per_turn"]
 rows.append("* the same with `evg_smart_actions` as the learner's decode; + `evg_smart_state_compact` in front — %.2f G, %.1f µs stream per turn; %.2f G, "
             "%.1f µs [`%s_bench_final.json`]"
             % (s["env_steps_per_s"] / 1e9, s["kernel_ms"] * 1e3, s["with_features"]["env_steps_per_s"] / 1e9, s["with_features"]["kernel_ms"] * 1e3, NAME))
+if s.get("with_features_fused"):
+    rows.append("* ... with the features written by the step launch itself (`evg_step_vs_policy_smart`) instead of the feature kernel — %.2f G, %.1f µs stream "
+                "per turn [`%s_bench_final.json`]" % (s["with_features_fused"]["env_steps_per_s"] / 1e9, s["with_features_fused"]["kernel_ms"] * 1e3, NAME))
 if s.get("with_epsilon"):
     rows.append("* the TRAINING turn: `evg_smart_get_action` (DQNAgent.get_action, epsilon %g: coin + get_random_actions on the device) instead of "
                 "`evg_smart_actions` — %.2f G, %.1f µs stream per turn [`%s_bench_final.json`]"

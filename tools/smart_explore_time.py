@@ -30,4 +30,10 @@ def timed(fn, reps=200):
 print("evg_smart_actions                 %.2f us per call" % timed(lambda: env.smart_actions(q, obs=sobs)))
 for eps in (0.0, 0.1, 1.0):
     print("evg_smart_get_action eps = %.1f    %.2f us per call" % (eps, timed(lambda: env.smart_get_action(q, eps, seat=0, obs=sobs))))
+sh = torch.empty((N, 34), device=env.device)
+sw = torch.empty((N, 12, 13), device=env.device)
+rows = env.random_actions_seat(0).clone()
+print("evg_step_vs_policy                %.2f us per call" % timed(lambda: env.step_vs("random", rows, seat=0)))
+print("evg_step_vs_policy_smart          %.2f us per call (the same turn + the Smart_State features of the new observation)" % timed(lambda: env.step_vs("random", rows, seat=0, features=(sh, sw))))
+print("evg_smart_state_compact           %.2f us per call (the separate feature kernel it replaces)" % timed(lambda: env.smart_state_compact(-1, sobs, sh, sw)))
 env.close()
