@@ -145,11 +145,16 @@ class PipelinedVecEnv(object):
         self._on_part(i, lambda: part.step(actions))
         return self.part_views(i)
 
-    def step_vs_part(self, i, policy, actions, seat=0):
+    def step_vs_part(self, i, policy, actions, seat=0, features=None):
         """The learner-seat turn (EvergladesVecEnv.step_vs) of part i: actions [n_i, 7, 2] or [n_i, 2, 7, 2]; the caller seat's
-        observation lands in obs_seat[part i]."""
+        observation lands in obs_seat[part i].  features=(shared [N, 34], swarm [N, 12, 13]): FULL-batch float32 tensors whose rows of part i the launch
+        also fills with the Smart_State features of the new observation (evg_step_vs_policy_smart; parts are whole wavefronts, so the slices are aligned)."""
         part = self.parts[i]
-        self._on_part(i, lambda: part.step_vs(policy, actions, seat=seat))
+        feats = None
+        if features is not None:
+            lo, n = self.ranges[i]
+            feats = (features[0][lo:lo + n], features[1][lo:lo + n])
+        self._on_part(i, lambda: part.step_vs(policy, actions, seat=seat, features=feats))
         return self.part_views(i, seat)
 
     def observe_seat(self, seat=0):

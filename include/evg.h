@@ -99,6 +99,13 @@ enum { EVG_RES_DEFENSE = 1, EVG_RES_OBSERVE = 2 };
  *   12 for group 11 of both players -- anything else is refused with EVG_ERR_INVALID (the unit TYPE of every group is free);
  *   total damage of an army (sum of size x unit damage) <= 255; max_turns 1..255;
  *   global env ids are 32-bit keys of the random streams: env_id_base + num_envs <= 2^32.
+ * PINNED AGAINST THE REFERENCE inside this domain (tests/golden/custom_*.npz: the imported reference playing on non-default map / unit files): directed
+ * distances incl. one-way edges and edges with different lengths per direction, control points up to 511, non-dyadic defenses, DEFENSE / OBSERVE on any
+ * node, bases on any two nodes, unit types in any order, a p1_node_map that is not its own inverse.  What this struct cannot express and a host parser must
+ * therefore refuse (everglades_amd.tables_from_json does): a node list that is not in ascending ID order (the reference's own fog mask then mixes list
+ * positions with IDs, server.py:409-418), a resource named 'DEFEND' (it would switch the reference's otherwise dead fortress bonus on, server.py:595 -- not
+ * modelled), fractional values where the tables hold integers (the reference would compute with the float).  max_turns other than 150 and p1_node_map
+ * other than DemoMap's have no file in the reference (hard-coded at server.py:321 and :89).
  */
 typedef struct evg_tables {
     int32_t node_dist[EVG_NUM_NODES + 1][EVG_NUM_NODES + 1];
@@ -282,6 +289,9 @@ EVG_API int evg_random_actions_seat(evg_handle* h, int seat, int32_t* actions_se
  * behaviour); their random draws (np.random.choice, np.random.shuffle, random.random) are keyed like every other
  * draw.  Order ids a bot emits outside [0, 11] (e.g. the -1 of cycle_target_node*.py) are passed
  * through; evg_step treats them like the reference's Python lists do.
+ * The bots route by THEIR OWN constants on every map: each file of agents/State_Machine/ carries DemoMap's NODE_CONNECTIONS (and TAR_NODE) as a module
+ * constant and never reads the map file, so on another map many of their orders are rejected by the server -- the reference's behaviour, reproduced
+ * (tests/golden/custom_agents.npz).
  * An agent is not consulted for a game that is over and not yet reset (status != 0 without auto-reset): the harness has left
  * that game's loop (evaluate.py:147-152), so its rows are zero and its object does not advance.
  * evg_scripted_reset re-creates all agent objects (first_turn, cycling position, attack list). */

@@ -2360,16 +2360,19 @@ def test_pipelined_learner_seat_parts_vs_oracle(evg, oracle_mod):
     o_obs = ora.reset()
     assert np.array_equal(_np(pipe.observe_seat(seat)).astype(np.float64), o_obs[:, seat])
     oa = np.zeros((N, 2, 7, 2), np.int32)
+    shared = torch.zeros((N, 34), device=pipe.device)                      # full-batch feature tensors: every part's launch fills its own rows
+    swarm = torch.zeros((N, 12, 13), device=pipe.device)
     for t in range(turns):
         for i in range(pipe.pipeline):
             pipe.wait_part(i, seat=seat)
-            pipe.step_vs_part(i, pol, pipe.random_actions_part(i, seat=seat), seat=seat)
+            pipe.step_vs_part(i, pol, pipe.random_actions_part(i, seat=seat), seat=seat, features=(shared, swarm) if t >= turns - 3 else None)
         ora.scripted_actions(pid, 1 - seat, o_obs, oa)
         oa[:, seat] = ora.random_actions()[:, seat]
         o_obs, _, _, o_info = ora.step(oa)
     pipe.wait_all()
     torch.cuda.synchronize()
     assert np.array_equal(_np(pipe.obs_seat).astype(np.float64), o_obs[:, seat]) and np.array_equal(_np(pipe.scores), o_info["scores"])
+    assert np.array_equal(_np(evg.EvergladesVecEnv.expand_smart_state(shared, swarm)), oracle_mod.smart_state(o_obs[:, seat]).astype(np.float32)), "fused features of the parts"
     check_state(pipe, ora.get_state(), "pipelined learner seat")
     ms = pipe.rollout_vs_free(30, pol, seat=seat, time_kernel=True)        # the free-running benchmark form continues the same games
     assert len(ms) == 3 and all(m > 0 for m in ms)

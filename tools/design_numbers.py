@@ -32,8 +32,8 @@ rows.append("* the default command under rocprofv3 — median timed region %s µ
             % (m.group(2), float(m.group(3)) * 1e3, slow[0] / 1e3, slow[1], fast[0] / 1e3, fast[1], slow[0] * slow[1] / 1e3, fast[0] * fast[1] / 1e3, NAME))
 bx6 = os.path.join(ROOT, "profiles", NAME + "_boxes.txt")
 if os.path.exists(bx6):
-    mm = re.search(r"default value over the four boxes: ([\d.]+)-([\d.]+) G = ([\d.]+) %; of the driver-shape value: ([\d.]+)-([\d.]+) G = ([\d.]+) %", open(bx6).read())
-    rows.append("* the same two commands on four boxes (separate gpurun calls) — default %s–%s G (%s %%: the boxes' sustained shader clocks differ, 2.30–2.38 GHz; "
+    mm = re.search(r"default value over the five boxes: ([\d.]+)-([\d.]+) G = ([\d.]+) %; of the driver-shape value: ([\d.]+)-([\d.]+) G = ([\d.]+) %", open(bx6).read())
+    rows.append("* the same two commands on five boxes (separate gpurun calls) — default %s–%s G (%s %%: the boxes' sustained shader clocks differ, 2.30–2.38 GHz; "
                 "the kernel's cycles do not), driver shape %s–%s G (%s %%) [`%s_boxes.txt`]" % (mm.group(1), mm.group(2), mm.group(3), mm.group(4), mm.group(5), mm.group(6), NAME))
 bx = os.path.join(ROOT, "profiles", NAME + "_driver_shape_boxes.txt")
 if os.path.exists(bx):
