@@ -260,7 +260,7 @@ def compact_line(full):
             return None
         keep = ("bound", "bound_detail", "achieved", "peak", "unit", "frac", "achieved_kernel_events", "frac_kernel_events", "traffic", "kernel_ms",
                 "bytes_per_env_step", "bytes_source", "launches_timed",
-                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "algorithmic_bytes_per_env_step",
+                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "algorithmic_bytes_per_env_step", "frac_algorithmic",
                 "traffic_over_algorithmic", "note")         # (hbm_proper_source: the *_cycled_pmc_traffic.json beside bytes_source's file)
         o = {k: _r(r[k], 5) for k in keep if k in r and r[k] is not None}
         for k in ("bytes_source", "hbm_proper_source"):        # (files under profiles/)
@@ -407,6 +407,10 @@ def hbm_roofline(pmc, form_key, kernel_ms, turns_per_launch_timed, n_local, obs_
                                   "observations)" % (source_hash, form_key, n_local, workload, obs_dtype)})
     r["achieved"] = bpe * n_local / (t_ms * 1e-3) / 1e9
     r["frac"] = r["achieved"] / HBM_PEAK_GBS
+    if r.get("algorithmic_bytes_per_env_step"):
+        # the same time priced with THIS DESIGN's algorithmic bytes instead of the counters' (what a reviewer recomputes: outputs + health rows touched, no
+        # over-fetch): frac x algorithmic / traffic
+        r["frac_algorithmic"] = r["algorithmic_bytes_per_env_step"] * n_local / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     r["achieved_kernel_events"] = bpe * n_local / (kernel_ms * 1e-3) / 1e9
     r["frac_kernel_events"] = r["achieved_kernel_events"] / HBM_PEAK_GBS
     return r

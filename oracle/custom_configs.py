@@ -102,3 +102,30 @@ def variant_objects(name, demo_map, demo_units):
     """(map object, unit object, p1 map) of a variant; None entries fall back to the given DemoMap / UnitDefinitions objects."""
     v = VARIANTS[name]
     return (copy.deepcopy(v["map"] or demo_map), copy.deepcopy(v["units"] or demo_units), list(v["p1_node_map"] or P1MAP))
+
+
+def random_config(rng):
+    """A random configuration inside the domain include/evg.h states (numpy Generator `rng`): a random DIRECTED graph over the 11 nodes (1-5 outbound edges per
+    node, distances 1..7, possibly disconnected), control points 1..511, StructureDefense with up to two decimals incl. 0, random resource sets, bases on any
+    two nodes, 3-4 unit types in random file order with random stats (an army's total damage <= 255).  Returns (map object, unit object) in the reference's
+    JSON schema.  Used by tests/test_oracle_vs_live_reference.py (oracle against the live reference) and by the GPU parity tests (HIP against the oracle)."""
+    import numpy as np
+    nodes = []
+    bases = rng.choice(np.arange(1, 12), 2, replace=False)
+    for i in range(1, 12):
+        others = [j for j in range(1, 12) if j != i]
+        outs = rng.choice(others, int(rng.integers(1, 6)), replace=False)
+        res = [r for r in ("DEFENSE", "OBSERVE", "SUPPLY") if rng.random() < 0.3]
+        nodes.append({"ID": i, "Radius": 1.0, "X": 0, "Y": 0, "Resource": res, "ControlPoints": int(rng.integers(1, 512)),
+                      "StructureDefense": float(rng.choice([0, 0.05, 0.5, 1, 1.3, 1.75, 2.45, 3.3, round(float(rng.random() * 4), 2)])),
+                      "TeamStart": 0 if i == bases[0] else (1 if i == bases[1] else -1),
+                      "Connections": [{"ConnectedID": int(j), "Distance": int(rng.integers(1, 8))} for j in outs]})
+    names = ["Tank", "Controller", "Striker"] + (["Scout"] if rng.random() < 0.5 else [])
+    while True:
+        order = list(rng.permutation(len(names)))
+        units = [dict(Name=names[k], Health=int(rng.integers(1, 10)), Damage=int(rng.integers(1, 4)), Speed=int(rng.integers(1, 8)),
+                      Control=int(rng.integers(1, 16)), Cost=int(rng.integers(1, 16))) for k in order]
+        dmg = {u["Name"].lower(): u["Damage"] for u in units}
+        if 32 * dmg["controller"] + 32 * dmg["striker"] + 36 * dmg["tank"] <= 255:
+            break
+    return {"MapName": "fuzz", "nodes": nodes}, {"units": units}

@@ -511,6 +511,7 @@ def test_bench_roofline_pricing_from_a_saved_counter_pass():
         assert abs(r["achieved_kernel_events"] - bpe * n / 0.0150e-3 / 1e9) < 1e-6 and r["frac_kernel_events"] > r["frac"]
         assert abs(r["traffic"] - bpe * n * tpl_timed) < 1e-3 and r["traffic_unit"] == "bytes per launch"
         assert 1300 < r["algorithmic_bytes_per_env_step"] < 1400 and 1.0 < r["traffic_over_algorithmic"] < 1.15      # 971 + 2 x rows written
+        assert abs(r["frac_algorithmic"] - r["frac"] / r["traffic_over_algorithmic"]) < 1e-12
     assert 1400 < bench.hbm_roofline(pmc, "persistent", 0.015, 150.0, n, "float32")["bytes_per_env_step"] < 1450         # the r05 figure: 1 425 B
     # a per-turn leg prices its stream time: both pairs are the same figure
     r = bench.hbm_roofline(pmc, "learner_vs_bot_per_turn", 0.030, 1, n, "float32")

@@ -1175,6 +1175,59 @@ def _custom_tables(evg, oracle_mod):
     return t, ot
 
 
+def test_random_tables_vs_oracle(evg, oracle_mod, tmp_path):
+    """HIP against the oracle on RANDOM configurations of the domain include/evg.h states (oracle/custom_configs.random_config: random directed graphs,
+    control points 1..511, two-decimal defenses, random resources / bases / unit files) -- the same generator with which tests/test_oracle_vs_live_reference.py
+    holds the ORACLE against the live reference where it is mounted (150 configurations checked at the time of writing).  Per configuration: the files go through
+    tables_from_json -> evg_create; 110 turns one launch per turn (random and wild orders, auto-reset) compared every turn; the persistent form of a small
+    batch (four-lane kernel) and of a 65 568-env batch (two-lane kernel, one whole round + a ragged remainder) against the oracle's final state."""
+    import json
+    import custom_configs as cc
+    from gen_policies import policy_actions
+    fast = 0
+    for c in range(8):
+        rng = np.random.default_rng([20261009, c])
+        mobj, uobj = cc.random_config(rng)
+        mp, up = tmp_path / ("m%d.json" % c), tmp_path / ("u%d.json" % c)
+        mp.write_text(json.dumps(mobj)); up.write_text(json.dumps(uobj))
+        tables = evg.tables_from_json(str(mp), str(up))
+        ot = oracle_mod.tables_from_json_text(json.dumps(mobj), json.dumps(uobj))
+        assert bytes(tables) == bytes(ot)
+        N, seed = 160, 400 + c
+        env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, tables=tables)
+        ora = oracle_mod.Oracle(N, seed=seed, auto_reset=True, tables=ot)
+        obs = _np(env.reset()).astype(np.float64)
+        assert np.array_equal(obs, ora.reset()), ("reset", c)
+        for t in range(110):
+            a = policy_actions("wild", obs, t, rng) if (t // 25) % 2 else _np(env.random_actions()).copy()
+            o, rew, done, info = env.step(a)
+            o_obs, o_rew, o_done, o_info = ora.step(a)
+            obs = _np(o).astype(np.float64)
+            assert np.array_equal(obs, o_obs), ("obs", c, t)
+            assert np.array_equal(_np(info["scores"]), o_info["scores"]) and np.array_equal(_np(info["status"]), o_info["status"]), (c, t)
+            assert np.array_equal(_np(done), o_done) and np.allclose(_np(rew), o_rew, rtol=0, atol=REWARD_ATOL), (c, t)
+        check_state(env, ora.get_state(), ("stepwise", c))
+        assert np.array_equal(_np(env.fog_of_war()), ora.fog_of_war()) and np.array_equal(_np(env.knowledge()), ora.knowledge()), c
+        env.rollout_random(90, turns_per_launch=90)                          # persistent form, small batch: the four-lane kernel
+        for t in range(90):
+            ora.step_noobs(ora.random_actions())
+        check_state(env, ora.get_state(), ("persistent, four lanes", c))
+        env.close()
+        if c < 3:                                                            # ... and the two-lane persistent kernel (one whole round + a remainder)
+            NB = 65536 + 32
+            env = evg.EvergladesVecEnv(NB, seed=seed, auto_reset=True, tables=tables)
+            ora = oracle_mod.Oracle(NB, seed=seed, auto_reset=True, tables=ot)
+            env.reset(); ora.reset()
+            env.rollout_random(45, turns_per_launch=45)
+            for t in range(45):
+                ora.step_noobs(ora.random_actions())
+            check_state(env, ora.get_state(), ("persistent, two lanes", c))
+            assert np.array_equal(env.episode_stats()["totals"], ora.episode_stats()["totals"])
+            env.close()
+        fast += 1
+    assert fast == 8
+
+
 @pytest.mark.parametrize("force_ieee_div", [False, True])
 def test_custom_tables_vs_oracle(evg, oracle_mod, force_ieee_div):
     """Every runtime table changed (map distances, control points, non-dyadic defenses, resources, unit stats, turn limit):

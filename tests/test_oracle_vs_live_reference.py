@@ -1,0 +1,74 @@
+"""CPU test, build container only: the oracle against the LIVE reference on RANDOM configurations.
+
+tests/golden/custom_*.npz pin three hand-made non-default map / unit files.  Where the reference is mounted (/root/reference: this container and the
+judge's, never the GPU box) this test goes further: it draws random configurations inside the domain include/evg.h states -- random DIRECTED graphs over the
+11 nodes (1-5 outbound edges per node, distances 1..7, possibly disconnected), control points 1..511, StructureDefense with up to two decimals incl. 0,
+random resource sets, bases on any two nodes, 3-4 unit types in random order with random stats (an army's total damage <= 255) -- writes them as the
+reference's JSON files, lets the imported reference play keyed-random and 'wild' order streams on them (oracle/gen_golden.py's Runner: the unmodified server
+with the keyed entropy source planted), and replays every turn through the oracle: observations, scores, status, float64 health bits, packed groups and
+nodes, per-node list order, fog mask, knowledge levels.  Runs in a fresh process (the reference loader plants a stand-in `gym` into sys.modules).
+Skipped where the reference is absent."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+REF = os.environ.get("EVG_REFERENCE", "/root/reference")
+
+_CHILD = r'''
+import json, os, sys, tempfile
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
+import gen_golden as gg
+import oracle as om
+from conftest import golden_initial_state
+
+from custom_configs import random_config
+
+seed0, count = int(sys.argv[2]), int(sys.argv[3])
+R = gg.Runner()
+saved = dict(R.cfg)
+tmp = tempfile.mkdtemp(prefix="evg_fuzz_")
+played = 0
+for c in range(count):
+    rng = np.random.default_rng([seed0, c])
+    mobj, uobj = random_config(rng)
+    mtxt, utxt = json.dumps(mobj), json.dumps(uobj)
+    mp, up = os.path.join(tmp, "m%d.json" % c), os.path.join(tmp, "u%d.json" % c)
+    open(mp, "w").write(mtxt); open(up, "w").write(utxt)
+    R.cfg = dict(saved, map_file=mp, unit_file=up)
+    T = om.tables_from_json_text(mtxt, utxt)
+    for pol in ("random", "wild"):
+        seed, env_id = 5000 + c, 3 * c + (pol == "wild")
+        g = R.play(pol, seed, env_id, 0, max_turns=60 if pol == "wild" else 150, obs_bound=511)
+        d = {k: v[None] for k, v in g.items() if k != "length"}
+        d.update(seed=np.array([seed]), env_id=np.array([env_id]), episode=np.array([0]), length=np.array([g["length"]]))
+        o = om.Oracle(1, seed=seed, env_id_base=env_id, tables=T)
+        obs = o.reset()
+        assert np.array_equal(obs[0], g["obs"][0].astype(np.float64)), ("reset obs", c, pol)
+        for t in range(g["length"]):
+            obs, reward, done, info = o.step(g["actions"][t][None].astype(np.int32))
+            what = (c, pol, t, mtxt, utxt)
+            assert np.array_equal(obs[0], g["obs"][t + 1].astype(np.float64)), ("obs",) + what
+            assert np.array_equal(info["scores"][0], g["scores"][t]) and info["status"][0] == g["status"][t] and done[0] == g["done"][t], ("scores / status",) + what
+            assert np.allclose(reward[0], g["reward"][t], rtol=0, atol=1e-12), ("reward",) + what
+            s = o.get_state()
+            assert np.array_equal(s["health"][0], g["health"][t + 1]), ("health bits",) + what
+            assert np.array_equal(s["groups"][0], g["groups"][t + 1]) and np.array_equal(s["nodes"][0], g["nodes"][t + 1]), ("state",) + what
+            assert np.array_equal(s["rank"][0], g["rank"][t + 1]), ("list order",) + what
+            assert np.array_equal(o.fog_of_war()[0], g["fog"][t + 1]) and np.array_equal(o.knowledge()[0], g["know"][t + 1]), ("fog / knowledge",) + what
+        played += g["length"]
+print("fuzz ok: %d configurations, %d turns" % (count, played))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "everglades-server")), reason="the reference is not mounted here (it never is on the GPU box)")
+def test_oracle_equals_the_live_reference_on_random_configurations(oracle_mod, tmp_path):
+    script = tmp_path / "fuzz_child.py"
+    script.write_text(_CHILD)
+    out = subprocess.run([sys.executable, str(script), ROOT, "20261008", "10"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "fuzz ok: 10 configurations" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
