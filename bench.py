@@ -260,7 +260,7 @@ def compact_line(full):
             return None
         keep = ("bound", "bound_detail", "achieved", "peak", "unit", "frac", "achieved_kernel_events", "frac_kernel_events", "traffic", "kernel_ms",
                 "bytes_per_env_step", "bytes_source", "launches_timed",
-                "turns_per_launch_timed", "survey_8d_frac", "hbm_proper_frac", "algorithmic_bytes_per_env_step", "frac_algorithmic",
+                "survey_8d_frac", "hbm_proper_frac", "frac_algorithmic",      # (algorithmic bytes = bytes_per_env_step / traffic_over_algorithmic)
                 "traffic_over_algorithmic", "note")         # (hbm_proper_source: the *_cycled_pmc_traffic.json beside bytes_source's file)
         o = {k: _r(r[k], 5) for k in keep if k in r and r[k] is not None}
         for k in ("bytes_source", "hbm_proper_source"):        # (files under profiles/)
