@@ -812,6 +812,18 @@ class Run(object):
                 "what": "%d launches of %d turns between one pair of barrier + synchronize brackets, right after the K-step regions (same handle, same games going on)"
                         % (args.sustained_launches, PHASES)}
 
+    def snapshot_games(self):
+        """The games as they stand right after the timed regions (and the sustained leg): the episode results and win counters the line reports, the rows the
+        single-rank "gather" returns, and -- bounded: at most 6 000 turns since the first reset -- the whole state the CPU oracle must reproduce afterwards."""
+        args = self.args
+        if self.env.check_fault():                           # (never expected: a chunk hand-over fault of a launch plan; raises)
+            raise SystemExit("fault")
+        self.stats = self.env.episode_stats()
+        if not self.dist_on:
+            self.gathered = self.gather(self.env.packed_episode_results())
+        self.played_at_snapshot = self.played
+        self.final_state = self.env.get_state() if (self.world == 1 and not args.no_cpu_baseline and args.workload == "random" and self.played <= 6000) else None
+
     # ------------------------------------------------------------------------------------------------------------------------------------------------
     def per_turn_leg(self, fused):
         """150 turns, one step launch per turn, warmed; wall clock between two barriers and the stream time between two events around the whole leg (so
@@ -1127,14 +1139,7 @@ def main(argv=None):
     if run.scratch is not None:
         run.scratch.close()
         run.scratch = None
-    if run.env.check_fault():                           # (never expected: a chunk hand-over fault of a launch plan; raises)
-        raise SystemExit("fault")
-    # the games as they stand right after the K-step regions: what the CPU replays (bounded: at most 6 000 turns since the first reset)
-    run.stats = run.env.episode_stats()
-    if not run.dist_on:
-        run.gathered = run.gather(run.env.packed_episode_results())
-    run.played_at_snapshot = run.played
-    run.final_state = run.env.get_state() if (run.world == 1 and not args.no_cpu_baseline and args.workload == "random" and run.played <= 6000) else None
+    run.snapshot_games()
     dist_block = None
     if run.dist_on:
         ident = device_identity(run.torch, run.dev_index, run.local_rank)
