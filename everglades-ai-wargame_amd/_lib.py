@@ -31,7 +31,7 @@ EXPORTS = ["evg_default_tables", "evg_create", "evg_destroy", "evg_reset", "evg_
            "evg_random_actions_seat", "evg_smart_state_seat", "evg_smart_state_compact", "evg_check_fault", "evg_rollout_vs_policy", "evg_fog_of_war",
            "evg_sightings", "evg_smart_state", "evg_smart_actions", "evg_smart_get_action", "evg_move_table", "evg_random_actions", "evg_rollout_random", "evg_rollout_policies",
            "evg_scripted_actions", "evg_scripted_reset",
-           "evg_get_state", "evg_set_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats",
+           "evg_get_state", "evg_set_state", "evg_get_run_state", "evg_set_run_state", "evg_seed_stock_entropy", "evg_get_stock_entropy", "evg_set_stock_entropy", "evg_episode_stats",
            "evg_episode_stats_device", "evg_pack_episode_results", "evg_pack_episode_results_counted", "evg_comm_unique_id", "evg_comm_init",
            "evg_gather_returns", "evg_comm_destroy", "evg_launch_plan", "evg_num_envs",
            "evg_state_bytes_per_env", "evg_last_error", "evg_abi_version"]
@@ -142,6 +142,8 @@ def load(path=None):
     L.evg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.evg_observe.argtypes = [vp, vp, vp]
     L.evg_step_vs_policy.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.evg_get_run_state.argtypes = [vp] * 7
+    L.evg_set_run_state.argtypes = [vp] * 7
     L.evg_step_vs_policy_smart.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.evg_observe_seat.argtypes = [vp, C.c_int, vp, vp]
     L.evg_random_actions_seat.argtypes = [vp, C.c_int, vp, vp]

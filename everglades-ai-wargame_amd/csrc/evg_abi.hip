@@ -1093,6 +1093,71 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
     return EVG_OK;
 }
 
+// What evg_get_state / evg_set_state do not carry and a RESUMED run needs: the scripted agents' objects, the running episode returns, the results of the last
+// finished episodes and the win counters (the reference never serialises its env; this is the build's own checkpoint).
+int evg_get_run_state(evg_handle* h, uint32_t* agents, float* running_returns, float* returns, int32_t* length, int8_t* winner, int64_t* totals) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    EVG_ON_DEVICE(h);
+    HIP_TRY(hipDeviceSynchronize());
+    { const int frc = check_fault(h); if (frc) return frc; }
+    const size_t N = (size_t)h->S.N;
+    if (agents) {                                            // device [2][N] x 3 arrays -> host [N][2][3]
+        std::vector<uint32_t> a(2 * N), b(2 * N), c(2 * N);
+        HIP_TRY(hipMemcpy(a.data(), h->S.agent_cycle, 2 * N * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b.data(), h->S.agent_swarm, 2 * N * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c.data(), h->S.agent_dfs, 2 * N * 4, hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < N; ++e)
+            for (size_t p = 0; p < 2; ++p) {
+                uint32_t* o = agents + (e * 2 + p) * 3;
+                o[0] = a[p * N + e]; o[1] = b[p * N + e]; o[2] = c[p * N + e];
+            }
+    }
+    if (running_returns) {                                   // device [2][N] -> host [N][2]
+        std::vector<float> r(2 * N);
+        HIP_TRY(hipMemcpy(r.data(), h->S.ep_ret, 2 * N * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t e = 0; e < N; ++e) { running_returns[2 * e] = r[e]; running_returns[2 * e + 1] = r[N + e]; }
+    }
+    if (returns) HIP_TRY(hipMemcpy(returns, h->S.fin_ret, 2 * N * sizeof(float), hipMemcpyDeviceToHost));
+    if (length) HIP_TRY(hipMemcpy(length, h->S.fin_len, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (winner) HIP_TRY(hipMemcpy(winner, h->S.fin_win, N, hipMemcpyDeviceToHost));
+    if (totals) HIP_TRY(hipMemcpy(totals, h->S.totals, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return EVG_OK;
+}
+
+int evg_set_run_state(evg_handle* h, const uint32_t* agents, const float* running_returns, const float* returns, const int32_t* length, const int8_t* winner,
+                      const int64_t* totals) {
+    if (!h) return fail(EVG_ERR_INVALID, "null handle");
+    EVG_ON_DEVICE(h);
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t)h->S.N;
+    if (winner)
+        for (size_t e = 0; e < N; ++e)
+            if (winner[e] < EVG_WINNER_NONE || winner[e] > EVG_WINNER_TIE) return fail(EVG_ERR_INVALID, "set_run_state: winner[%zu] = %d", e, (int)winner[e]);
+    if (totals && (totals[0] < 0 || totals[1] < 0 || totals[2] < 0 || totals[3] < 0 || totals[1] + totals[2] + totals[3] != totals[0]))
+        return fail(EVG_ERR_INVALID, "set_run_state: totals must be {episodes, p0 wins, p1 wins, ties} with episodes = the sum of the other three");
+    if (agents) {
+        std::vector<uint32_t> a(2 * N), b(2 * N), c(2 * N);
+        for (size_t e = 0; e < N; ++e)
+            for (size_t p = 0; p < 2; ++p) {
+                const uint32_t* o = agents + (e * 2 + p) * 3;
+                a[p * N + e] = o[0]; b[p * N + e] = o[1]; c[p * N + e] = o[2];
+            }
+        HIP_TRY(hipMemcpy(h->S.agent_cycle, a.data(), 2 * N * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->S.agent_swarm, b.data(), 2 * N * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->S.agent_dfs, c.data(), 2 * N * 4, hipMemcpyHostToDevice));
+    }
+    if (running_returns) {
+        std::vector<float> r(2 * N);
+        for (size_t e = 0; e < N; ++e) { r[e] = running_returns[2 * e]; r[N + e] = running_returns[2 * e + 1]; }
+        HIP_TRY(hipMemcpy(h->S.ep_ret, r.data(), 2 * N * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (returns) HIP_TRY(hipMemcpy(h->S.fin_ret, returns, 2 * N * sizeof(float), hipMemcpyHostToDevice));
+    if (length) HIP_TRY(hipMemcpy(h->S.fin_len, length, N * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (winner) HIP_TRY(hipMemcpy(h->S.fin_win, winner, N, hipMemcpyHostToDevice));
+    if (totals) HIP_TRY(hipMemcpy(h->S.totals, totals, 4 * sizeof(int64_t), hipMemcpyHostToDevice));
+    return EVG_OK;
+}
+
 #ifdef EVG_DIAG
 /* Diagnostic libraries only (libevg_diag.so / libevg_stamps.so; declared in no public header).
  *   ablate          bit0 orders, bit1 combat, bit2 movement, bit4 observation write-out, bit5 state store are skipped; bit6: a chunked launch never

@@ -499,6 +499,45 @@ class EvergladesVecEnv(object):
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self._check(self.L.evg_set_state(self._h, p(g), p(n), p(h), p(e)))
 
+    def get_run_state(self):
+        """What get_state() does not carry and a resumed run needs (evg_get_run_state): the scripted agents' objects uint32 [N, 2, 3], the running episode
+        returns float32 [N, 2], the results of the last finished episodes (returns, length, winner) and the win counters (totals)."""
+        N = self.num_envs
+        d = dict(agents=np.zeros((N, 2, 3), np.uint32), running_returns=np.zeros((N, 2), np.float32), returns=np.zeros((N, 2), np.float32),
+                 length=np.zeros(N, np.int32), winner=np.zeros(N, np.int8), totals=np.zeros(4, np.int64))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self.L.evg_get_run_state(self._h, p(d["agents"]), p(d["running_returns"]), p(d["returns"]), p(d["length"]), p(d["winner"]), p(d["totals"])))
+        return d
+
+    def set_run_state(self, agents=None, running_returns=None, returns=None, length=None, winner=None, totals=None):
+        N = self.num_envs
+
+        def arr(a, dtype, shape, name):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype)
+            if a.shape != shape:
+                raise ValueError("set_run_state: %s must have shape %s, got %s" % (name, shape, a.shape))
+            return a
+        keep = [arr(agents, np.uint32, (N, 2, 3), "agents"), arr(running_returns, np.float32, (N, 2), "running_returns"), arr(returns, np.float32, (N, 2), "returns"),
+                arr(length, np.int32, (N,), "length"), arr(winner, np.int8, (N,), "winner"), arr(totals, np.int64, (4,), "totals")]
+        self._check(self.L.evg_set_run_state(self._h, *[None if a is None else a.ctypes.data_as(C.c_void_p) for a in keep]))
+
+    def checkpoint(self):
+        """Everything a handle created with the same arguments needs to continue this run bit for bit: get_state() + get_run_state() (+ the generators of the
+        stock-entropy mode).  Host arrays (numpy): np.savez-able."""
+        ck = dict(state=self.get_state(), run=self.get_run_state())
+        if self.rng_mode == "mt19937":
+            ck["entropy"] = self.get_stock_entropy()
+        return ck
+
+    def restore(self, ck):
+        s = ck["state"]
+        self.set_state(s["groups"], s["nodes"], s["health"], s["env"])
+        self.set_run_state(**ck["run"])
+        if "entropy" in ck:
+            self.set_stock_entropy(ck["entropy"])
+
     def seed_stock_entropy(self, seeds=None):
         """rng_mode="mt19937": np.random.seed(seeds[e]) for every env (None: the create-time rule seed + env_id_base + e)."""
         a = None

@@ -38,7 +38,8 @@ extern "C" {
 
 #define EVG_ABI_VERSION 6
 /* 6: evg_smart_get_action (DQNAgent.get_action with epsilon > 0), evg_step_vs_policy_smart (the learner-seat turn that also writes the Smart_State
- *    features); reward / score buffers need 8-byte alignment only (5 asked 16 of every buffer)
+ *    features), evg_get_run_state / evg_set_run_state (agent objects, returns, win counters: checkpoint / resume); reward / score buffers need 8-byte
+ *    alignment only (5 asked 16 of every buffer)
  * 5: evg_smart_actions; evg_comm_unique_id / evg_comm_init / evg_gather_returns / evg_comm_destroy + EVG_ERR_COMM; every device buffer must be
  *    16-byte aligned (checked)
  * 4: evg_step_vs_policy / evg_observe_seat / evg_rollout_vs_policy / evg_random_actions_seat / evg_smart_state_seat, evg_smart_state_compact,
@@ -378,6 +379,19 @@ EVG_API int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* n
 EVG_API int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream);
 EVG_API int evg_get_stock_entropy(evg_handle* h, uint32_t* out);
 EVG_API int evg_set_stock_entropy(evg_handle* h, const uint32_t* in);
+
+/* Checkpoint / resume of a RUNNING job: what evg_get_state / evg_set_state do not carry.  (the reference never serialises its env; its agents
+ * pickle their own networks.  A handle restored with evg_set_state + evg_set_run_state -- + evg_set_stock_entropy in the stock mode -- on a handle created
+ * with the same config continues bit for bit like the one that was saved: tests/test_gpu_parity.py::test_checkpoint_resume_continues_bit_for_bit.)
+ * HOST pointers; the calls synchronise; any pointer may be NULL; evg_set_state zeroes the running returns, so restore the run state AFTER it.
+ *   agents           uint32 [N][2][3]: the scripted agents' objects per (env, player) -- {first_turn / group_num / node_num word, SwarmAgent's attack list,
+ *                    dfs_attack's call counter} (alive across episodes like the reference's agent objects, evaluate.py:85-93)
+ *   running_returns  float [N][2]: the sum of rewards of the episode in progress
+ *   returns, length, winner, totals: the arrays of evg_episode_stats (results of the last finished episode per env; episodes / wins since create)
+ * evg_get_run_state fails with EVG_ERR_FAULT on a faulted handle, like evg_get_state. */
+EVG_API int evg_get_run_state(evg_handle* h, uint32_t* agents, float* running_returns, float* returns, int32_t* length, int8_t* winner, int64_t* totals);
+EVG_API int evg_set_run_state(evg_handle* h, const uint32_t* agents, const float* running_returns, const float* returns, const int32_t* length,
+                              const int8_t* winner, const int64_t* totals);
 
 /* Per-env results of the most recently finished episode, and running totals (device -> host copy,
  * synchronises).  Any pointer may be NULL.

@@ -803,6 +803,69 @@ def test_smart_get_action_with_epsilon_matches_reference_fixture_and_oracle(evg,
     env.close()
 
 
+@pytest.mark.parametrize("mode", ["fused bots, persistent", "learner seat, per turn", "stock entropy"])
+def test_checkpoint_resume_continues_bit_for_bit(evg, tmp_path, mode):
+    """Checkpoint / resume of a running job (the reference never serialises its env): EvergladesVecEnv.checkpoint() = evg_get_state +
+    evg_get_run_state (scripted agents' objects, running returns, last finished episodes, win counters; + the generators in the stock-entropy mode), saved
+    with np.savez, loaded into a FRESH handle of the same config, continues exactly like the run that was saved: observations, orders, state, episode results."""
+    import torch
+    N, seed = 4096 + 40, 77
+    kw = dict(seed=seed, auto_reset=True, env_id_base=500)
+    if mode == "stock entropy":
+        N, kw = 96, dict(kw, rng_mode="mt19937")
+
+    def play(env, turns):
+        out = None
+        if mode == "fused bots, persistent":
+            env.rollout_policies(turns, "dfs_attack", "swarm", fused=True, turns_per_launch=turns)      # both bots carry state across turns AND episodes
+            out = (_np(env.obs).copy(), _np(env._actions).copy())
+        elif mode == "learner seat, per turn":
+            for _ in range(turns):
+                sobs, rew, done, info = env.step_vs("cycle_target_node", env.random_actions_seat(1), seat=1)
+            out = (_np(sobs).copy(), _np(rew).copy())
+        else:
+            for _ in range(turns):
+                obs, rew, done, info = env.step(env.random_actions())
+            out = (_np(obs).copy(), _np(rew).copy())
+        return out
+
+    a = evg.EvergladesVecEnv(N, **kw)
+    a.reset()
+    play(a, 95)                                                            # config-5-like bots end games around turn 91-95: some envs are in their second episode
+    ck = a.checkpoint()
+    flat = {"%s/%s" % (k, kk): vv for k, v in ck.items() for kk, vv in (v.items() if isinstance(v, dict) else [("", v)])}
+    np.savez(tmp_path / "ck.npz", **flat)
+    want = play(a, 70)
+    want_state, want_stats = a.get_state(), a.episode_stats()
+    a.close()
+    ld = np.load(tmp_path / "ck.npz")
+    ck2 = {}
+    for k in ld.files:
+        top, sub = k.split("/")
+        if sub:
+            ck2.setdefault(top, {})[sub] = ld[k]
+        else:
+            ck2[top] = ld[k]
+    b = evg.EvergladesVecEnv(N, **kw)
+    b.reset()
+    b.restore(ck2)
+    got = play(b, 70)
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y), mode
+    check_state(b, want_state, mode)
+    st = b.episode_stats()
+    for k in ("returns", "length", "winner", "totals"):
+        assert np.array_equal(st[k], want_stats[k]), (mode, k)
+    assert int(st["totals"][0]) > 0
+    r = b.get_run_state()
+    assert r["agents"].shape == (N, 2, 3) and (mode != "fused bots, persistent" or (r["agents"][:, 0, 2] > 0).all())       # dfs_attack's call counter did advance
+    with pytest.raises(evg.EvgError):
+        b.set_run_state(totals=np.array([5, 1, 1, 1], np.int64))            # episodes != wins + ties: refused
+    with pytest.raises(ValueError):
+        b.set_run_state(agents=np.zeros((N, 2, 2), np.uint32))
+    b.close()
+
+
 @pytest.mark.parametrize("tpl", [2, 7, 150])
 def test_persistent_multi_turn_rollout_equals_stepwise(evg, oracle_mod, tpl):
     """The persistent rollout form (each launch plays `tpl` consecutive turns per wavefront with the state resident on
