@@ -46,14 +46,28 @@ def kernel_source_files():
     return files + [os.path.join(os.path.dirname(HERE), "include", "evg.h")]
 
 
+_C_TOKEN = None
+
+
+def _code_only(text):
+    """C / C++ source without comments and with runs of white space collapsed (string and character literals kept as they are): what the compiler sees."""
+    global _C_TOKEN
+    import re
+    if _C_TOKEN is None:
+        _C_TOKEN = re.compile(r'''("(?:\\.|[^"\\])*"|'(?:\\.|[^'\\])*')|(/\*.*?\*/|//[^\n]*)''', re.S)
+    text = _C_TOKEN.sub(lambda m: m.group(1) if m.group(1) is not None else " ", text)
+    return " ".join(text.split())
+
+
 def kernel_source_hash():
-    """Identifies the kernel sources a libevg.so was built from: the counter passes committed under profiles/ carry it, and bench.py uses
-    only figures whose hash equals the one of the tree it runs in (the ONE definition: bench.py and tools/_prof.py call this)."""
+    """Identifies the kernel CODE a libevg.so was built from: the counter passes committed under profiles/ carry it, and bench.py uses
+    only figures whose hash equals the one of the tree it runs in (the ONE definition: bench.py and tools/_prof.py call this).  Comments and white space
+    are not part of it (round 6: a documentation change in include/evg.h used to invalidate every counter pass)."""
     import hashlib
     h = hashlib.sha256()
     for f in kernel_source_files():
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -617,3 +617,16 @@ def test_both_lane_mappings_cite_the_same_reference_lines():
         for rng in want:
             assert rng in c2, ("two-lane fragments, phase %d: no citation of lines %d-%d" % ((k,) + rng))
             assert rng in c4, ("evg_step4.inc, phase %d: no citation of lines %d-%d" % ((k,) + rng))
+
+
+def test_kernel_source_hash_is_about_code_not_comments(evg, tmp_path):
+    """The hash that ties a counter pass under profiles/ to a build covers the kernel CODE: comments and white space do not change it (a documentation change
+    in include/evg.h must not invalidate the evidence), any token does; string and character literals are kept verbatim."""
+    L = evg._lib
+    a = 'int f(int x) { return x + 1; }  // adds one\n/* block\n comment */ const char* s = "// kept /* kept */";\n'
+    b = 'int   f(int x)\n{\n    return x + 1;   /* another comment */ }\nconst char* s = "// kept /* kept */";'
+    assert L._code_only(a) == L._code_only(b)
+    assert L._code_only(a) != L._code_only(a.replace("x + 1", "x + 2")) and L._code_only(a) != L._code_only(a.replace("// kept", "// Kept"))
+    assert L._code_only("char c = '\\\"'; // q") == "char c = '\\\"';"
+    h = L.kernel_source_hash()
+    assert len(h) == 16 and h == L.kernel_source_hash()
