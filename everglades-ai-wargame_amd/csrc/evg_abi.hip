@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 #include "evg_device.h"
@@ -223,6 +225,15 @@ static int launch_rollout(evg_handle* h, const StepIO& io, hipStream_t s) {
     hipGraphExec_t exec = caller_captures ? nullptr : graph_of(h, io);
     if (!exec) return launch_step(h->S, io, h->cfg.obs_dtype, h->caps, s);
     return (int)hipGraphLaunch(exec, s);
+}
+
+// "No C++ exception crosses the ABI" (include/evg.h): every int-returning entry point below is a function-try-block that ends here.  The only exceptions the
+// host code of this file can raise are allocation failures of its std::vector / std::string temporaries.
+static int on_exception() noexcept {
+    try { throw; }
+    catch (const std::bad_alloc&) { return fail(EVG_ERR_ALLOC, "out of host memory"); }
+    catch (const std::exception& e) { return fail(EVG_ERR_INVALID, "unexpected C++ exception: %s", e.what()); }
+    catch (...) { return fail(EVG_ERR_INVALID, "unexpected C++ exception"); }
 }
 
 extern "C" {
@@ -459,7 +470,7 @@ static int build_dev_tables(const evg_config* cfg, DevTables* D) {
     return EVG_OK;
 }
 
-int evg_create(const evg_config* cfg, evg_handle** out) {
+int evg_create(const evg_config* cfg, evg_handle** out) try {
     if (!cfg || !out) return fail(EVG_ERR_INVALID, "null argument");
     *out = nullptr;
     if (cfg->struct_size != sizeof(evg_config) || cfg->abi_version != EVG_ABI_VERSION)
@@ -595,7 +606,7 @@ int evg_create(const evg_config* cfg, evg_handle** out) {
     if (e != hipSuccess) { evg_destroy(h); return fail(EVG_ERR_HIP, "state initialisation failed: %s", hipGetErrorString(e)); }
     *out = h;
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 void evg_destroy(evg_handle* h) {
     if (!h) return;
@@ -611,22 +622,22 @@ void evg_destroy(evg_handle* h) {
 
 int evg_num_envs(const evg_handle* h) { return h ? h->S.N : 0; }
 
-int evg_state_bytes_per_env(const evg_handle* h) {
+int evg_state_bytes_per_env(const evg_handle* h) try {
     (void)h;
     return kStateBytesPerEnv;       // grp, stamp, node, env, episode, health, ep_ret (evg_device.h)
-}
+} catch (...) { return on_exception(); }
 
-int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream) {
+int evg_reset(evg_handle* h, const uint8_t* mask, void* obs_out, void* stream) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     EVG_NEED_ALIGNED16(obs_out);
     EVG_ON_DEVICE(h);
     const int rc = launch_reset(h->S, mask, obs_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "reset launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward_out, uint8_t* done_out, int8_t* winner_out,
-             int32_t* scores_out, uint8_t* status_out, void* stream) {
+             int32_t* scores_out, uint8_t* status_out, void* stream) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!actions || !reward_out || !done_out) return fail(EVG_ERR_INVALID, "actions, reward_out and done_out are required");
     EVG_NEED_ALIGNED16(actions); EVG_NEED_ALIGNED16(obs_out); EVG_NEED_ALIGNED8(reward_out); EVG_NEED_ALIGNED8(scores_out);
@@ -635,9 +646,9 @@ int evg_step(evg_handle* h, const int32_t* actions, void* obs_out, float* reward
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
     if (rc) return fail(EVG_ERR_HIP, "step launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_observe(evg_handle* h, void* obs_out, void* stream) {
+int evg_observe(evg_handle* h, void* obs_out, void* stream) try {
     if (!h || !obs_out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_NEED_ALIGNED16(obs_out);
     EVG_ON_DEVICE(h);
@@ -645,7 +656,7 @@ int evg_observe(evg_handle* h, void* obs_out, void* stream) {
     const int rc = launch_step(h->S, io, h->cfg.obs_dtype, h->caps, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 static int step_vs_policy_impl(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out,
                                float* shared_out, float* swarm_out, float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out,
@@ -666,20 +677,20 @@ static int step_vs_policy_impl(evg_handle* h, int seat, const int32_t* actions, 
 }
 
 int evg_step_vs_policy(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out, float* reward_out,
-                       uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream) {
+                       uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, void* stream) try {
     return step_vs_policy_impl(h, seat, actions, actions_both_seats, opponent_policy, obs_seat_out, nullptr, nullptr, reward_out, done_out, winner_out, scores_out,
                                status_out, stream);
-}
+} catch (...) { return on_exception(); }
 
 int evg_step_vs_policy_smart(evg_handle* h, int seat, const int32_t* actions, int actions_both_seats, int opponent_policy, void* obs_seat_out,
                              float* shared_out, float* swarm_out, float* reward_out, uint8_t* done_out, int8_t* winner_out, int32_t* scores_out,
-                             uint8_t* status_out, void* stream) {
+                             uint8_t* status_out, void* stream) try {
     if (!shared_out || !swarm_out) return fail(EVG_ERR_INVALID, "evg_step_vs_policy_smart: shared_out and swarm_out are required (evg_step_vs_policy is the form without)");
     return step_vs_policy_impl(h, seat, actions, actions_both_seats, opponent_policy, obs_seat_out, shared_out, swarm_out, reward_out, done_out, winner_out,
                                scores_out, status_out, stream);
-}
+} catch (...) { return on_exception(); }
 
-int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream) {
+int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream) try {
     if (!h || !obs_seat_out || seat < 0 || seat > 1) return fail(EVG_ERR_INVALID, "bad argument");
     EVG_NEED_ALIGNED16(obs_seat_out);
     if (h->S.mt_key) return fail(EVG_ERR_INVALID, "evg_observe_seat: keyed-Philox handles only");
@@ -689,27 +700,27 @@ int evg_observe_seat(evg_handle* h, int seat, void* obs_seat_out, void* stream) 
     const int rc = launch_step_seat(h->S, io, h->cfg.obs_dtype, h->caps, stream);
     if (rc) return fail(EVG_ERR_HIP, "observe launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) {
+int evg_random_actions(evg_handle* h, int32_t* actions_out, void* stream) try {
     if (!h || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_NEED_ALIGNED16(actions_out);
     EVG_ON_DEVICE(h);
     const int rc = launch_random_actions(h->S, actions_out, -1, stream);
     if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_random_actions_seat(evg_handle* h, int seat, int32_t* actions_seat_out, void* stream) {
+int evg_random_actions_seat(evg_handle* h, int seat, int32_t* actions_seat_out, void* stream) try {
     if (!h || !actions_seat_out || seat < 0 || seat > 1) return fail(EVG_ERR_INVALID, "bad argument");
     EVG_NEED_ALIGNED16(actions_seat_out);
     EVG_ON_DEVICE(h);
     const int rc = launch_random_actions(h->S, actions_seat_out, seat, stream);
     if (rc) return fail(EVG_ERR_HIP, "random_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream) {
+int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs, int32_t* actions_out, void* stream) try {
     if (!h || !obs || !actions_out) return fail(EVG_ERR_INVALID, "null argument");
     if (policy < 0 || policy >= EVG_POLICY_COUNT || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "policy/player out of range");
     EVG_NEED_ALIGNED16(obs); EVG_NEED_ALIGNED16(actions_out);
@@ -717,43 +728,43 @@ int evg_scripted_actions(evg_handle* h, int policy, int player, const void* obs,
     const int rc = launch_scripted_actions(h->S, policy, player, obs, actions_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "scripted_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void* stream) {
+int evg_fog_of_war(evg_handle* h, uint8_t* fog_out, uint8_t* knowledge_out, void* stream) try {
     if (!h || (!fog_out && !knowledge_out)) return fail(EVG_ERR_INVALID, "null argument");
     EVG_ON_DEVICE(h);
     const int rc = launch_fog(h->S, fog_out, knowledge_out, nullptr, stream);
     if (rc) return fail(EVG_ERR_HIP, "fog launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream) {
+int evg_sightings(evg_handle* h, int8_t* sight_out, void* stream) try {
     if (!h || !sight_out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_ON_DEVICE(h);
     const int rc = launch_fog(h->S, nullptr, nullptr, sight_out, stream);
     if (rc) return fail(EVG_ERR_HIP, "sightings launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream) {
+int evg_smart_state(evg_handle* h, int player, const void* obs, float* features_out, void* stream) try {
     if (!h || !obs || !features_out || player < 0 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
     EVG_NEED_ALIGNED16(features_out); EVG_NEED_ALIGNED16(obs);
     EVG_ON_DEVICE(h);
     const int rc = launch_smart_state(h->S, player, obs, 0, features_out, nullptr, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_out, void* stream) {
+int evg_smart_state_seat(evg_handle* h, const void* obs_seat, float* features_out, void* stream) try {
     if (!h || !obs_seat || !features_out) return fail(EVG_ERR_INVALID, "bad argument");
     EVG_NEED_ALIGNED16(features_out); EVG_NEED_ALIGNED16(obs_seat);
     EVG_ON_DEVICE(h);
     const int rc = launch_smart_state(h->S, 0, obs_seat, 1, features_out, nullptr, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_smart_state_compact(evg_handle* h, int player, const void* obs, float* shared_out, float* swarm_out, void* stream) {
+int evg_smart_state_compact(evg_handle* h, int player, const void* obs, float* shared_out, float* swarm_out, void* stream) try {
     if (!h || !obs || !shared_out || !swarm_out || player < -1 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
     if ((reinterpret_cast<uintptr_t>(shared_out) & 7u) != 0) return fail(EVG_ERR_INVALID, "shared_out must be 8-byte aligned");
     EVG_NEED_ALIGNED16(swarm_out); EVG_NEED_ALIGNED16(obs);
@@ -761,19 +772,19 @@ int evg_smart_state_compact(evg_handle* h, int player, const void* obs, float* s
     const int rc = launch_smart_state(h->S, player < 0 ? 0 : player, obs, player < 0 ? 1 : 0, shared_out, swarm_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_state launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_smart_actions(evg_handle* h, int player, const void* obs, const float* q, int32_t* actions_out, int32_t* directions_out, void* stream) {
+int evg_smart_actions(evg_handle* h, int player, const void* obs, const float* q, int32_t* actions_out, int32_t* directions_out, void* stream) try {
     if (!h || !obs || !q || !actions_out || player < -1 || player > 1) return fail(EVG_ERR_INVALID, "bad argument");
     EVG_NEED_ALIGNED16(obs); EVG_NEED_ALIGNED16(q); EVG_NEED_ALIGNED16(actions_out); EVG_NEED_ALIGNED16(directions_out);
     EVG_ON_DEVICE(h);
     const int rc = launch_smart_actions(h->S, player < 0 ? 0 : player, obs, player < 0 ? 1 : 0, q, actions_out, directions_out, h->cfg.obs_dtype, stream);
     if (rc) return fail(EVG_ERR_HIP, "smart_actions launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 int evg_smart_get_action(evg_handle* h, int seat, int obs_one_seat, const void* obs, const float* q, float epsilon, const float* epsilon_env,
-                         int32_t* actions_out, int32_t* directions_out, uint8_t* explored_out, void* stream) {
+                         int32_t* actions_out, int32_t* directions_out, uint8_t* explored_out, void* stream) try {
     if (!h || !obs || !q || !actions_out || seat < 0 || seat > 1) return fail(EVG_ERR_INVALID, "bad argument");
     if (!epsilon_env && !(epsilon >= 0.0f && epsilon <= 1.0f)) return fail(EVG_ERR_INVALID, "epsilon %g outside [0, 1]", (double)epsilon);
     EVG_NEED_ALIGNED16(obs); EVG_NEED_ALIGNED16(q); EVG_NEED_ALIGNED16(actions_out); EVG_NEED_ALIGNED16(directions_out);
@@ -782,7 +793,7 @@ int evg_smart_get_action(evg_handle* h, int seat, int obs_one_seat, const void* 
     const int rc = launch_smart_actions(h->S, seat, obs, obs_one_seat ? 1 : 0, q, actions_out, directions_out, h->cfg.obs_dtype, stream, &ex);
     if (rc) return fail(EVG_ERR_HIP, "smart_get_action launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 void evg_move_table(int32_t* table /* [11][5] */) {
     // agents/Smart_State/Move_Translation.py:3-97: node reached from (0-indexed) node n0 in direction 0 left, 1 right, 2 up, 3 down, 4 stay
@@ -791,31 +802,31 @@ void evg_move_table(int32_t* table /* [11][5] */) {
     for (int n = 0; n < 11; ++n) for (int d = 0; d < 5; ++d) table[n * 5 + d] = T[d][n];
 }
 
-int evg_scripted_reset(evg_handle* h, void* stream) {
+int evg_scripted_reset(evg_handle* h, void* stream) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     EVG_ON_DEVICE(h);
     const int rc = launch_scripted_reset(h->S, stream);
     if (rc) return fail(EVG_ERR_HIP, "scripted_reset launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
                         uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream);
 
 int evg_rollout_random(evg_handle* h, int steps, int fused, int32_t* actions_buf, void* obs_out, float* reward_out, uint8_t* done_out,
-                       int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
+                       int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) try {
     return rollout_impl(h, steps, fused, EVG_POLICY_RANDOM, EVG_POLICY_RANDOM, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out,
                         status_out, step_kernel_ms, stream);
-}
+} catch (...) { return on_exception(); }
 
 int evg_rollout_policies(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
-                         uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
+                         uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) try {
     if (policy0 < 0 || policy0 >= EVG_POLICY_COUNT || policy1 < 0 || policy1 >= EVG_POLICY_COUNT)
         return fail(EVG_ERR_INVALID, "policy out of range");
     if (!obs_out && !fused) return fail(EVG_ERR_INVALID, "rollout_policies: obs_out is required (the agents read it)");
     return rollout_impl(h, steps, fused, policy0, policy1, actions_buf, obs_out, reward_out, done_out, winner_out, scores_out, status_out,
                         step_kernel_ms, stream);
-}
+} catch (...) { return on_exception(); }
 
 static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int policy1, int32_t* actions_buf, void* obs_out, float* reward_out,
                         uint8_t* done_out, int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
@@ -907,7 +918,7 @@ static int rollout_impl(evg_handle* h, int steps, int fused, int policy0, int po
 
 int evg_rollout_vs_policy(evg_handle* h, int steps, int seat, int opponent_policy, int32_t* actions_seat_buf, void* obs_seat_out, float* reward_out,
                           uint8_t* done_out,
-                          int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) {
+                          int8_t* winner_out, int32_t* scores_out, uint8_t* status_out, float* step_kernel_ms, void* stream) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (steps < 1 || !actions_seat_buf || !obs_seat_out || !reward_out || !done_out)
         return fail(EVG_ERR_INVALID, "rollout_vs_policy: steps >= 1, actions_seat_buf, obs_seat_out, reward_out, done_out required");
@@ -939,9 +950,9 @@ int evg_rollout_vs_policy(evg_handle* h, int steps, int seat, int opponent_polic
         return check_fault(h);
     }
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream) {
+int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
     EVG_ON_DEVICE(h);
@@ -955,9 +966,9 @@ int evg_seed_stock_entropy(evg_handle* h, const uint32_t* seeds, void* stream) {
     const int rc = launch_mt_seed(h->S, d_seeds, stream);
     if (rc) return fail(EVG_ERR_HIP, "seed launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_get_stock_entropy(evg_handle* h, uint32_t* out) {
+int evg_get_stock_entropy(evg_handle* h, uint32_t* out) try {
     if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
     if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
     EVG_ON_DEVICE(h);
@@ -971,9 +982,9 @@ int evg_get_stock_entropy(evg_handle* h, uint32_t* out) {
         out[e * (MT_N + 1) + MT_N] = pos[e];
     }
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_set_stock_entropy(evg_handle* h, const uint32_t* in) {
+int evg_set_stock_entropy(evg_handle* h, const uint32_t* in) try {
     if (!h || !in) return fail(EVG_ERR_INVALID, "null argument");
     if (!h->S.mt_key) return fail(EVG_ERR_INVALID, "handle was not created with rng_mode = EVG_RNG_STOCK_MT19937");
     EVG_ON_DEVICE(h);
@@ -988,9 +999,9 @@ int evg_set_stock_entropy(evg_handle* h, const uint32_t* in) {
     HIP_TRY(hipMemcpy(h->S.mt_key, k.data(), k.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->S.mt_pos, pos.data(), N * 4, hipMemcpyHostToDevice));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health, int32_t* env) {
+int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health, int32_t* env) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
@@ -1032,9 +1043,9 @@ int evg_get_state(evg_handle* h, int32_t* groups, int32_t* nodes, double* health
         }
     }
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, const double* health, const int32_t* env) {
+int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, const double* health, const int32_t* env) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!groups || !nodes || !health || !env) return fail(EVG_ERR_INVALID, "set_state needs all four arrays");
     EVG_ON_DEVICE(h);
@@ -1078,9 +1089,9 @@ int evg_set_state(evg_handle* h, const int32_t* groups, const int32_t* nodes, co
     HIP_TRY(hipMemset(h->S.ep_ret, 0, 2 * N * sizeof(float)));
     HIP_TRY(hipDeviceSynchronize());
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* winner, int64_t* totals) {
+int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* winner, int64_t* totals) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
@@ -1091,11 +1102,11 @@ int evg_episode_stats(evg_handle* h, float* returns, int32_t* length, int8_t* wi
     if (winner) HIP_TRY(hipMemcpy(winner, h->S.fin_win, N, hipMemcpyDeviceToHost));
     if (totals) HIP_TRY(hipMemcpy(totals, h->S.totals, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 // What evg_get_state / evg_set_state do not carry and a RESUMED run needs: the scripted agents' objects, the running episode returns, the results of the last
 // finished episodes and the win counters (the reference never serialises its env; this is the build's own checkpoint).
-int evg_get_run_state(evg_handle* h, uint32_t* agents, float* running_returns, float* returns, int32_t* length, int8_t* winner, int64_t* totals) {
+int evg_get_run_state(evg_handle* h, uint32_t* agents, float* running_returns, float* returns, int32_t* length, int8_t* winner, int64_t* totals) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
@@ -1122,10 +1133,10 @@ int evg_get_run_state(evg_handle* h, uint32_t* agents, float* running_returns, f
     if (winner) HIP_TRY(hipMemcpy(winner, h->S.fin_win, N, hipMemcpyDeviceToHost));
     if (totals) HIP_TRY(hipMemcpy(totals, h->S.totals, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 int evg_set_run_state(evg_handle* h, const uint32_t* agents, const float* running_returns, const float* returns, const int32_t* length, const int8_t* winner,
-                      const int64_t* totals) {
+                      const int64_t* totals) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
@@ -1156,7 +1167,7 @@ int evg_set_run_state(evg_handle* h, const uint32_t* agents, const float* runnin
     if (winner) HIP_TRY(hipMemcpy(h->S.fin_win, winner, N, hipMemcpyHostToDevice));
     if (totals) HIP_TRY(hipMemcpy(h->S.totals, totals, 4 * sizeof(int64_t), hipMemcpyHostToDevice));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 #ifdef EVG_DIAG
 /* Diagnostic libraries only (libevg_diag.so / libevg_stamps.so; declared in no public header).
@@ -1170,7 +1181,7 @@ int evg_set_run_state(evg_handle* h, const uint32_t* agents, const float* runnin
  *                   launch forms), 32 (16 envs per wavefront + 32 helper lanes), 4 (the four-lanes-per-env kernel in both launch forms) or 256 (single-turn
  *                   launches as 256-thread workgroups of four independent wavefronts: the round-5 dispatch experiment)
  *   force_ieee_div  != 0: run the step kernel's true-division branch although the table set passed the exact-quotient check */
-EVG_API int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) {
+EVG_API int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wave, int force_ieee_div) try {
     if (!h || (lanes_per_wave != 0 && lanes_per_wave != 32 && lanes_per_wave != 64 && lanes_per_wave != 4 && lanes_per_wave != 2 && lanes_per_wave != 256))
         return fail(EVG_ERR_INVALID, "diag: bad argument");
     EVG_ON_DEVICE(h);
@@ -1184,21 +1195,21 @@ EVG_API int evg_diag_configure(evg_handle* h, uint32_t ablate, int lanes_per_wav
         HIP_TRY(hipMemcpy(h->d_tables, &h->host_tables, sizeof(DevTables), hipMemcpyHostToDevice));
     }
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 #endif
 
 #ifdef EVG_STAMPS
 /* stamps build only: per-workgroup s_memtime stamps of the last step launch, [blocks][16] */
-EVG_API int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) {
+EVG_API int evg_debug_read_stamps(evg_handle* h, unsigned long long* out) try {
     if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->stamps, (size_t)((h->S.N + 15) / 16) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 #endif
 
-int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen) {
+int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int buflen) try {
     if (!h || !buf || buflen < 1 || turns_per_launch < 1) return fail(EVG_ERR_INVALID, "launch_plan: bad argument");
     // the plan of the default rollout: observations written, orders recorded (the pointers are only tested against NULL)
     StepIO io = make_io(h, nullptr, reinterpret_cast<void*>(16), nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, 0, reinterpret_cast<int32_t*>(16));
@@ -1240,18 +1251,18 @@ int evg_launch_plan(const evg_handle* h, int turns_per_launch, char* buf, int bu
     s += tmp;
     snprintf(buf, (size_t)buflen, "%s", s.c_str());
     return p.n;
-}
+} catch (...) { return on_exception(); }
 
-int evg_pack_episode_results(evg_handle* h, float* out, void* stream) {
+int evg_pack_episode_results(evg_handle* h, float* out, void* stream) try {
     if (!h || !out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_NEED_ALIGNED16(out);
     EVG_ON_DEVICE(h);
     const int rc = launch_pack_results(h->S, out, nullptr, stream);
     if (rc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t* counts_out, void* stream) {
+int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t* counts_out, void* stream) try {
     if (!h || !out || !counts_out) return fail(EVG_ERR_INVALID, "null argument");
     EVG_NEED_ALIGNED16(out);
     if ((reinterpret_cast<uintptr_t>(counts_out) & 7u) != 0) return fail(EVG_ERR_INVALID, "counts_out must be 8-byte aligned");
@@ -1259,7 +1270,7 @@ int evg_pack_episode_results_counted(evg_handle* h, float* out, int64_t* counts_
     const int rc = launch_pack_results(h->S, out, reinterpret_cast<long long*>(counts_out), stream);
     if (rc) return fail(EVG_ERR_HIP, "pack launch failed: %s", hipGetErrorString((hipError_t)rc));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 // ---------------------------------------------------------------------------------------------
 // The path's one exchange between GPUs for callers that have no torch.distributed (SURVEY 8b `evg_gather_returns`, 8e): RCCL itself, opened at run time.
@@ -1317,7 +1328,7 @@ const RcclApi* rccl() {
     } while (0)
 }  // namespace
 
-int evg_comm_unique_id(void* id_out) {
+int evg_comm_unique_id(void* id_out) try {
     if (!id_out) return fail(EVG_ERR_INVALID, "null argument");
     const RcclApi* R = rccl();
     if (!R) return fail(EVG_ERR_COMM, "RCCL is not available: %s", g_rccl.why.c_str());
@@ -1326,9 +1337,9 @@ int evg_comm_unique_id(void* id_out) {
     RCCL_TRY(R, R->GetUniqueId(&id));
     memcpy(id_out, &id, sizeof(id));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_comm_init(evg_handle* h, const void* id, int world, int rank, const int32_t* counts) {
+int evg_comm_init(evg_handle* h, const void* id, int world, int rank, const int32_t* counts) try {
     if (!h || !id || !counts || world < 1 || rank < 0 || rank >= world) return fail(EVG_ERR_INVALID, "comm_init: bad argument");
     if (h->comm) return fail(EVG_ERR_INVALID, "comm_init: the handle already has a communicator (evg_comm_destroy first)");
     long long total = 0;
@@ -1352,9 +1363,9 @@ int evg_comm_init(evg_handle* h, const void* id, int world, int rank, const int3
     h->comm = c; h->comm_world = world; h->comm_rank = rank;
     h->comm_counts.assign(counts, counts + world);
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_gather_returns(evg_handle* h, int root, float* recv_out, void* stream) {
+int evg_gather_returns(evg_handle* h, int root, float* recv_out, void* stream) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!h->comm) return fail(EVG_ERR_INVALID, "gather_returns: no communicator (evg_comm_init)");
     if (root < 0 || root >= h->comm_world) return fail(EVG_ERR_INVALID, "gather_returns: root %d of %d ranks", root, h->comm_world);
@@ -1381,9 +1392,9 @@ int evg_gather_returns(evg_handle* h, int root, float* recv_out, void* stream) {
     if (r1 != ncclSuccess) return fail(EVG_ERR_COMM, "ncclSend / ncclRecv failed: %s", R->GetErrorString(r1));
     if (r2 != ncclSuccess) return fail(EVG_ERR_COMM, "ncclGroupEnd failed: %s", R->GetErrorString(r2));
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_comm_destroy(evg_handle* h) {
+int evg_comm_destroy(evg_handle* h) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     if (!h->comm) return EVG_OK;
     const RcclApi* R = rccl();
@@ -1393,16 +1404,16 @@ int evg_comm_destroy(evg_handle* h) {
     h->comm = nullptr; h->comm_world = 0; h->comm_rank = -1;
     h->comm_counts.clear();
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
-int evg_check_fault(evg_handle* h, uint32_t* fault_out) {
+int evg_check_fault(evg_handle* h, uint32_t* fault_out) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     EVG_ON_DEVICE(h);
     HIP_TRY(hipDeviceSynchronize());
     return check_fault(h, fault_out);
-}
+} catch (...) { return on_exception(); }
 
-int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner) {
+int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, int8_t** winner) try {
     if (!h) return fail(EVG_ERR_INVALID, "null handle");
     // no synchronisation here (the pointers are handed out once and read on the caller's streams): a fault already seen is reported; one of work still in
     // flight shows in evg_pack_episode_results' poisoned rows or in evg_check_fault
@@ -1411,6 +1422,6 @@ int evg_episode_stats_device(evg_handle* h, float** returns, int32_t** length, i
     if (length) *length = h->S.fin_len;
     if (winner) *winner = h->S.fin_win;
     return EVG_OK;
-}
+} catch (...) { return on_exception(); }
 
 }  // extern "C"

@@ -630,3 +630,28 @@ def test_kernel_source_hash_is_about_code_not_comments(evg, tmp_path):
     assert L._code_only("char c = '\\\"'; // q") == "char c = '\\\"';"
     h = L.kernel_source_hash()
     assert len(h) == 16 and h == L.kernel_source_hash()
+
+
+def test_no_cpp_exception_can_cross_the_abi():
+    """include/evg.h promises that no C++ exception crosses the ABI.  The host side allocates std::vector / std::string temporaries (state exchange, launch-plan
+    text, the RCCL loader), so every multi-line int-returning entry point of csrc/evg_abi.hip is a function-try-block ending in on_exception(), which maps
+    std::bad_alloc to EVG_ERR_ALLOC; the one-liners (evg_abi_version, evg_num_envs) allocate nothing."""
+    src = open(os.path.join(ROOT, "everglades-ai-wargame_amd", "csrc", "evg_abi.hip")).read().split("\n")
+    defs, guarded = [], []
+    for i, line in enumerate(src):
+        m = re.match(r"^(EVG_API )?int (evg_\w+)\(", line)
+        if not m or line.rstrip().endswith(";") or line.rstrip().endswith("}"):
+            continue
+        j = i
+        while not (src[j].rstrip().endswith(") {") or src[j].rstrip().endswith(") try {")):
+            j += 1
+        defs.append(m.group(2))
+        if src[j].rstrip().endswith(") try {"):
+            k = j + 1
+            while not src[k].startswith("}"):
+                k += 1
+            assert src[k] == "} catch (...) { return on_exception(); }", (m.group(2), src[k])
+            guarded.append(m.group(2))
+    assert len(defs) >= 40 and defs == guarded, sorted(set(defs) - set(guarded))
+    text = "\n".join(src)
+    assert "catch (const std::bad_alloc&) { return fail(EVG_ERR_ALLOC" in text
