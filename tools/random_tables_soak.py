@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""One-off soak (not a test): HIP against the oracle on MANY random configurations (oracle/custom_configs.random_config), every launch form.
+usage (on the GPU box): python tools/random_tables_soak.py [first] [count]"""
+import json, os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import everglades_amd as evg
+import oracle as om
+import custom_configs as cc
+from gen_policies import policy_actions
+
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 60)
+tmp = tempfile.mkdtemp()
+om.lib().evo_set_num_threads(16)
+fast = 0
+for c in range(first, first + count):
+    rng = np.random.default_rng([20261010, c])
+    mobj, uobj = cc.random_config(rng)
+    mp, up = os.path.join(tmp, "m.json"), os.path.join(tmp, "u.json")
+    open(mp, "w").write(json.dumps(mobj)); open(up, "w").write(json.dumps(uobj))
+    tables = evg.tables_from_json(mp, up)
+    ot = om.tables_from_json_text(json.dumps(mobj), json.dumps(uobj))
+    N, seed = 192, 900 + c
+    env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, tables=tables)
+    ora = om.Oracle(N, seed=seed, auto_reset=True, tables=ot)
+    obs = env.reset().cpu().numpy().astype(np.float64)
+    assert np.array_equal(obs, ora.reset()), ("reset", c)
+    for t in range(160):
+        a = policy_actions("wild", obs, t, rng) if (t // 20) % 3 == 1 else env.random_actions().cpu().numpy().copy()
+        o, rew, done, info = env.step(a)
+        o_obs, o_rew, o_done, o_info = ora.step(a)
+        obs = o.cpu().numpy().astype(np.float64)
+        assert np.array_equal(obs, o_obs), ("obs", c, t)
+        assert np.array_equal(info["scores"].cpu().numpy(), o_info["scores"]) and np.array_equal(done.cpu().numpy(), o_done), (c, t)
+    s, os_ = env.get_state(), ora.get_state()
+    assert all(np.array_equal(s[k], os_[k]) for k in ("groups", "nodes", "health", "env")), ("state", c)
+    assert np.array_equal(env.fog_of_war().cpu().numpy(), ora.fog_of_war()) and np.array_equal(env.knowledge().cpu().numpy(), ora.knowledge()), ("fog", c)
+    assert np.array_equal(env.sightings().cpu().numpy(), ora.sightings()), ("sightings", c)
+    env.rollout_random(100, turns_per_launch=100)
+    for t in range(100):
+        ora.step_noobs(ora.random_actions())
+    s, os_ = env.get_state(), ora.get_state()
+    assert all(np.array_equal(s[k], os_[k]) for k in ("groups", "nodes", "health", "env")), ("persistent state", c)
+    env.close()
+    if c % 10 == 0:
+        print("config", c, "ok", flush=True)
+print("soak ok: %d random configurations" % count)
