@@ -2529,3 +2529,30 @@ def test_graph_replay_build_plays_the_same_games(evg, oracle_mod):
         _compare_whole_batch(env, ora, o_obs, ("graph replay build", N))
         assert env.check_fault() == 0
         env.close()
+
+
+def test_smart_state_loop_example_runs_and_its_compact_network_equals_the_expanded_one(evg, oracle_mod):
+    """examples/smart_state_loop.py: the Smart_State learner's acting loop with everything but the network on the device.  The example evaluates its stand-in
+    network on the COMPACT features; here the same weights on the expanded [N, 12, 59] matrix give the same Q values (to float32 rounding of the re-associated
+    sums), and the loop plays whole episodes."""
+    import importlib.util
+    import torch
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("evg_example_smart", os.path.join(ROOT, "examples", "smart_state_loop.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    st = ex.main(num_envs=2048 + 5, turns=170, epsilon=0.25, opponent="cycle_rush_turn25", seat=1, seed=4)
+    assert int(st["totals"][0]) >= 2048 and int(st["totals"][1:].sum()) == int(st["totals"][0])
+    env = evg.EvergladesVecEnv(777, seed=2, auto_reset=True)
+    env.reset()
+    env.rollout_random(50, turns_per_launch=50)
+    sh, sw = env.smart_state_compact(0)
+    full = evg.EvergladesVecEnv.expand_smart_state(sh, sw)                      # [N, 12, 59]
+    net = ex.make_network(env.device, seed=0)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    w1 = (torch.randn((60, 59), generator=g) * 0.2).to(env.device)
+    w2 = (torch.randn((60, 60), generator=g) * 0.2).to(env.device)
+    w3 = (torch.randn((5, 60), generator=g) * 0.2).to(env.device)
+    want = torch.relu(torch.relu(full @ w1.T) @ w2.T) @ w3.T
+    assert torch.allclose(net(sh, sw), want, rtol=1e-4, atol=1e-4)
+    env.close()
