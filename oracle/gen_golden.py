@@ -9,7 +9,7 @@ reference itself is written: the fixtures hold action streams, observations, rew
 scores, status and state snapshots (numbers), which is what the parity tests replay
 through the C oracle and through the HIP path.
 
-    python oracle/gen_golden.py            # regenerate everything but the 10 000-match sample (about 2 minutes)
+    python oracle/gen_golden.py            # regenerate everything but the two 10 000-match samples (about 16 minutes, 12 of them the custom_var* fixtures)
     EVG_GOLDEN_ONLY=matches python oracle/gen_golden.py    # tests/golden/matches_10k.npz (about 10 minutes on 6 cores)
     EVG_GOLDEN_ONLY=matches5 python oracle/gen_golden.py   # tests/golden/matches_config5_10k.npz (Cycle_BRush_Turn25 vs SwarmAgent)
     EVG_GOLDEN_ONLY=custom python oracle/gen_golden.py     # tests/golden/custom_var{A,B,C}.npz (non-default map / unit files; 4 minutes)
