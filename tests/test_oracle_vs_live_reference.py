@@ -66,6 +66,67 @@ print("fuzz ok: %d configurations, %d turns" % (count, played))
 '''
 
 
+_AGENT_CHILD = r'''
+import json, os, sys, tempfile
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
+import gen_golden as gg
+import oracle as om
+from custom_configs import random_config
+
+B = dict(swarm=("swarm_agent.py", "SwarmAgent"), cyc25=("cycle_rush_turn25.py", "Cycle_BRush_Turn25"), cyc50=("cycle_rush_turn50.py", "Cycle_BRush_Turn50"),
+         dfs=("dfs_attack.py", "dfs_attack"), ctn=("cycle_target_node.py", "Cycle_Target_Node"), ctn1=("cycle_target_node1.py", "cycle_targetedNode1"),
+         ctn11=("cycle_target_node11.py", "cycle_targetedNode11"), ctnp2=("cycle_target_node11P2.py", "cycle_targetedNode11P2"), bull=("bull_rush.py", "bull_rush"),
+         brv1=("base_rush_v1.py", "base_rushV1"), allc=("all_cycle.py", "all_cycle"), rnd=("random_actions.py", "random_actions"),
+         delay=("random_actions_delay.py", "random_actions_delay"), same=("same_commands.py", "same_commands"))
+names = sorted(B)
+seed0, count = int(sys.argv[2]), int(sys.argv[3])
+R = gg.Runner()
+saved = dict(R.cfg)
+tmp = tempfile.mkdtemp(prefix="evg_fuzz_agents_")
+turns = 0
+for c in range(count):
+    rng = np.random.default_rng([seed0, c])
+    mobj, uobj = random_config(rng)
+    mtxt, utxt = json.dumps(mobj), json.dumps(uobj)
+    mp, up = os.path.join(tmp, "m%d.json" % c), os.path.join(tmp, "u%d.json" % c)
+    open(mp, "w").write(mtxt); open(up, "w").write(utxt)
+    R.cfg = dict(saved, map_file=mp, unit_file=up)
+    a, b = (names[int(i)] for i in rng.integers(0, len(names), 2))
+    seed, env_id = 6000 + c, 2 * c + 1
+    d = gg.play_agents(R, (B[a], B[b]), seed, env_id, 2)                # the reference's own agent classes, objects alive across both episodes
+    pol = [gg.AGENT_POLICY[B[a][1]], gg.AGENT_POLICY[B[b][1]]]
+    o = om.Oracle(1, seed=seed, env_id_base=env_id, tables=om.tables_from_json_text(mtxt, utxt))
+    for ep in range(2):
+        obs = o.reset()
+        T = int(d["length"][ep])
+        for t in range(T):
+            what = (c, a, b, ep, t)
+            assert np.array_equal(obs[0], d["obs"][ep, t].astype(np.float64)), ("obs",) + what
+            act = np.zeros((1, 2, 7, 2), np.int32)
+            o.scripted_actions(pol[0], 0, obs, act)
+            o.scripted_actions(pol[1], 1, obs, act)
+            assert np.array_equal(act[0], d["actions"][ep, t]), ("orders",) + what + (act[0].tolist(), d["actions"][ep, t].tolist())
+            obs, rew, done, info = o.step(act)
+        assert done[0] == 1 and info["status"][0] == d["status"][ep] and np.array_equal(info["scores"][0], d["scores"][ep]), ("ending", c, a, b, ep)
+        turns += T
+R.cfg = saved
+print("agent fuzz ok: %d configurations, %d turns" % (count, turns))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "everglades-server")), reason="the reference is not mounted here (it never is on the GPU box)")
+def test_oracle_bots_equal_the_live_reference_agents_on_random_configurations(oracle_mod, tmp_path):
+    """The same for the scripted opponents: random pairings of the reference's own agent classes (14 of agents/State_Machine/) on random maps / unit files,
+    two consecutive episodes with the agent objects kept alive -- the oracle's bots emit the same orders, turn by turn, and the games end alike.  (The bots route
+    by their own DemoMap constants whatever the map is; on a random map most of their orders are rejected by the server.)"""
+    script = tmp_path / "fuzz_agents_child.py"
+    script.write_text(_AGENT_CHILD)
+    out = subprocess.run([sys.executable, str(script), ROOT, "20261011", "12"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "agent fuzz ok: 12 configurations" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "everglades-server")), reason="the reference is not mounted here (it never is on the GPU box)")
 def test_oracle_equals_the_live_reference_on_random_configurations(oracle_mod, tmp_path):
     script = tmp_path / "fuzz_child.py"

@@ -43,6 +43,31 @@ for c in range(first, first + count):
         ora.step_noobs(ora.random_actions())
     s, os_ = env.get_state(), ora.get_state()
     assert all(np.array_equal(s[k], os_[k]) for k in ("groups", "nodes", "health", "env")), ("persistent state", c)
+    # ... and the scripted bots on the same tables: a random pairing through evg_scripted_actions (from the observation tensor) and then fused into the
+    # persistent kernel (from the on-chip state), against the oracle's bots (held to the reference's agent classes on random maps by
+    # tests/test_oracle_vs_live_reference.py)
+    P = evg.EvergladesVecEnv.POLICIES
+    names = [n for n in evg._lib.POLICY_NAMES if n != "no_action"]
+    pa, pb = (names[int(i)] for i in rng.integers(0, len(names), 2))
+    env.scripted_reset(); ora.scripted_reset()
+    o_obs = ora.observe()
+    env.observe()
+    oa = np.zeros((N, 2, 7, 2), np.int32)
+    for t in range(60):
+        env.scripted_actions(pa, 0)
+        a = env.scripted_actions(pb, 1)
+        ora.scripted_actions(P[pa], 0, o_obs, oa); ora.scripted_actions(P[pb], 1, o_obs, oa)
+        assert np.array_equal(a.cpu().numpy(), oa), ("bot orders", c, pa, pb, t)
+        o, rew, done, info = env.step(a)
+        o_obs, _, _, _ = ora.step(oa)
+        assert np.array_equal(o.cpu().numpy().astype(np.float64), o_obs), ("bot obs", c, pa, pb, t)
+    env.rollout_policies(70, pa, pb, fused=True, turns_per_launch=70)
+    for t in range(70):
+        ora.scripted_actions(P[pa], 0, o_obs, oa); ora.scripted_actions(P[pb], 1, o_obs, oa)
+        o_obs, _, _, _ = ora.step(oa)
+    s, os_ = env.get_state(), ora.get_state()
+    assert all(np.array_equal(s[k], os_[k]) for k in ("groups", "nodes", "health", "env")), ("fused bots state", c, pa, pb)
+    assert np.array_equal(env._actions.cpu().numpy(), oa), ("fused bots orders", c, pa, pb)
     env.close()
     if c % 10 == 0:
         print("config", c, "ok", flush=True)
