@@ -116,6 +116,81 @@ print("agent fuzz ok: %d configurations, %d turns" % (count, turns))
 '''
 
 
+_SMART_CHILD = r'''
+import os, sys, types
+import numpy as np
+root, ref = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, ref)
+import rng_spec
+import oracle as om
+import torch
+import agents.Smart_State.DQNAgent as D
+
+rng = np.random.default_rng(int(sys.argv[3]))
+M = int(sys.argv[4])
+# random but well-formed observations of one player: turn, 11 x (flags, control, opposing units), 12 x (node, type, avg health, in transit, alive)
+obs = np.zeros((M, 105))
+obs[:, 0] = rng.integers(0, 151, M)
+for n in range(11):
+    obs[:, 1 + 4 * n] = rng.integers(0, 2, M); obs[:, 2 + 4 * n] = rng.integers(0, 2, M)
+    obs[:, 3 + 4 * n] = rng.integers(-500, 501, M); obs[:, 4 + 4 * n] = rng.integers(0, 101, M)
+for k in range(12):
+    obs[:, 45 + 5 * k] = rng.integers(1, 12, M); obs[:, 46 + 5 * k] = rng.integers(0, 3, M); obs[:, 47 + 5 * k] = rng.integers(0, 101, M)
+    obs[:, 48 + 5 * k] = rng.integers(0, 2, M); obs[:, 49 + 5 * k] = rng.integers(0, 13, M)
+q = rng.standard_normal((M, 12, 5)).astype(np.float32)
+q[M // 2:] = np.round(q[M // 2:] * 2) / 2                                # ties between swarms and between directions
+eps = rng.choice(np.array([0.0, 0.05, 0.3, 0.7, 1.0], np.float32), M)
+seed, player = 99, int(rng.integers(0, 2))
+cur = dict(m=0)
+
+class _Std(object):
+    def random(self):
+        L = sys._getframe(1).f_locals
+        return rng_spec.explore_draws(seed, cur["m"], cur["m"] % 5, int(L["obs"][0]), player)[0] / 4294967296.0
+
+class _NpRandom(object):
+    def choice(self, a, size, replace=True):
+        L = sys._getframe(1).f_locals
+        coin, swarms, dirs = rng_spec.explore_draws(seed, cur["m"], cur["m"] % 5, int(L["obs"][0]), player)
+        return np.array(swarms if a == 12 else dirs)
+
+class _Np(object):
+    random = _NpRandom()
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+D.random, D.np = _Std(), _Np()
+agent = D.DQNAgent.__new__(D.DQNAgent)
+agent.num_nodes = 11
+ns = types.SimpleNamespace(num_nodes=11)
+acts, dirs, feats = np.zeros((M, 7, 2), np.int32), np.zeros((M, 7, 2), np.int32), np.zeros((M, 12, 59))
+for m in range(M):
+    cur["m"] = m
+    agent.epsilon = float(eps[m])
+    agent.policy_net = lambda so, m=m: torch.from_numpy(q[m, int(np.argmax(so[47:59]))].copy())
+    a, d = agent.get_action(obs[m])
+    acts[m], dirs[m] = a.astype(np.int32), d.astype(np.int32)
+    al = D.DQNAgent.get_allies_on_node_data(ns, obs[m])
+    for sw in range(12):
+        feats[m, sw] = D.DQNAgent.create_swarm_obs(ns, sw, obs[m], al)
+ga, gd, gx = om.smart_get_action(q, obs, seed, np.arange(M, dtype=np.uint32), (np.arange(M) % 5).astype(np.uint32), player, eps)
+assert np.array_equal(ga, acts) and np.array_equal(gd, dirs), "get_action"
+assert np.array_equal(om.smart_state(obs), feats), "create_swarm_obs"
+print("smart fuzz ok: %d agent calls, %d explored" % (M, int(gx.sum())))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "agents", "Smart_State")), reason="the reference is not mounted here (it never is on the GPU box)")
+def test_oracle_smart_state_agent_equals_the_live_reference_on_random_inputs(oracle_mod, tmp_path):
+    """DQNAgent.create_swarm_obs and DQNAgent.get_action (epsilon coin, get_random_actions, get_best_actions) of the LIVE reference on 1 500 random
+    observations / Q tensors / epsilons against the oracle's restatements (the three draws served from the keyed stream by module proxies, as in
+    oracle/gen_golden.py)."""
+    script = tmp_path / "fuzz_smart_child.py"
+    script.write_text(_SMART_CHILD)
+    out = subprocess.run([sys.executable, str(script), ROOT, REF, "5", "1500"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "smart fuzz ok: 1500 agent calls" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "everglades-server")), reason="the reference is not mounted here (it never is on the GPU box)")
 def test_oracle_bots_equal_the_live_reference_agents_on_random_configurations(oracle_mod, tmp_path):
     """The same for the scripted opponents: random pairings of the reference's own agent classes (14 of agents/State_Machine/) on random maps / unit files,
