@@ -508,14 +508,18 @@ def device_identity(torch, dev_index, local_rank):
 
 
 def check_distinct_devices(identities, backend, rehearsal):
-    """N ranks of a real run must sit on N distinct GPUs.  The identity compared is the strongest one available (uuid, else PCI address, else the ordinal);
-    a rehearsal on one GPU (one-rank group, or gloo ranks sharing the card) only records the answer."""
-    key = "uuid" if all(i.get("uuid") for i in identities) else ("pci" if all(i.get("pci") for i in identities) else "device_index")
-    ids = [i[key] for i in identities]
-    distinct = len(set(ids)) == len(ids)
+    """N ranks of a real run must sit on N distinct GPUs.  The identities compared are the hardware ones this torch build exposes (uuid, PCI address; the
+    ordinal only when it exposes neither): the ranks count as distinct when ONE of them tells them all apart (a driver that reports one placeholder uuid
+    for every card must not end the run while the PCI addresses differ), and as shared when none does.  A rehearsal on one GPU (one-rank group, or gloo
+    ranks sharing the card) only records the answer."""
+    keys = [k for k in ("uuid", "pci") if all(i.get(k) for i in identities)] or ["device_index"]
+    seen = {k: len(set(i[k] for i in identities)) for k in keys}
+    key = next((k for k in keys if seen[k] == len(identities)), keys[0])
+    distinct = seen[key] == len(identities)
     if not distinct and backend == "nccl" and not rehearsal:
-        raise SystemExit("%d ranks but only %d distinct GPUs (%s = %s): not a one-rank-per-GPU run" % (len(ids), len(set(ids)), key, ids))
-    return {"distinct_devices": distinct, "identified_by": key, "devices_seen": len(set(ids))}
+        raise SystemExit("%d ranks but only %d distinct GPUs (%s = %s): not a one-rank-per-GPU run"
+                         % (len(identities), seen[key], key, [i[key] for i in identities]))
+    return {"distinct_devices": distinct, "identified_by": key, "devices_seen": seen[key]}
 
 
 # =====================================================================================================================================================

@@ -547,6 +547,8 @@ def test_bench_line_says_where_every_rank_sat_and_what_the_reference_does():
     assert bench.check_distinct_devices(ids, "nccl", False) == {"distinct_devices": True, "identified_by": "uuid", "devices_seen": 8}
     no_uuid = [dict(i, uuid=None) for i in ids]
     assert bench.check_distinct_devices(no_uuid, "nccl", False)["identified_by"] == "pci"
+    placeholder = [dict(i, uuid="00000000-0000-0000-0000-000000000000") for i in ids]                      # one uuid for every card, PCI addresses differ: still N GPUs
+    assert bench.check_distinct_devices(placeholder, "nccl", False) == {"distinct_devices": True, "identified_by": "pci", "devices_seen": 8}
     twice = [ids[0], dict(ids[0], local_rank=1)]
     with pytest.raises(SystemExit):
         bench.check_distinct_devices(twice, "nccl", False)                     # two RCCL ranks on one GPU: not a one-rank-per-GPU run
