@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak (not a test): HIP against the oracle on MANY random configurations (oracle/custom_configs.random_config), every launch form.
-usage (on the GPU box): python tools/random_tables_soak.py [first] [count]"""
+usage (on the GPU box): python tools/random_tables_soak.py [first] [count] [envs]     (envs > 4096: the two-lane kernels; fewer stepwise turns)"""
 import json, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +12,8 @@ import custom_configs as cc
 from gen_policies import policy_actions
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 60)
+ENVS = int(sys.argv[3]) if len(sys.argv) > 3 else 192
+STEPWISE, BOTWISE = (160, 60) if ENVS <= 4096 else (30, 12)
 tmp = tempfile.mkdtemp()
 om.lib().evo_set_num_threads(16)
 fast = 0
@@ -22,12 +24,12 @@ for c in range(first, first + count):
     open(mp, "w").write(json.dumps(mobj)); open(up, "w").write(json.dumps(uobj))
     tables = evg.tables_from_json(mp, up)
     ot = om.tables_from_json_text(json.dumps(mobj), json.dumps(uobj))
-    N, seed = 192, 900 + c
+    N, seed = ENVS, 900 + c
     env = evg.EvergladesVecEnv(N, seed=seed, auto_reset=True, tables=tables)
     ora = om.Oracle(N, seed=seed, auto_reset=True, tables=ot)
     obs = env.reset().cpu().numpy().astype(np.float64)
     assert np.array_equal(obs, ora.reset()), ("reset", c)
-    for t in range(160):
+    for t in range(STEPWISE):
         a = policy_actions("wild", obs, t, rng) if (t // 20) % 3 == 1 else env.random_actions().cpu().numpy().copy()
         o, rew, done, info = env.step(a)
         o_obs, o_rew, o_done, o_info = ora.step(a)
@@ -53,7 +55,7 @@ for c in range(first, first + count):
     o_obs = ora.observe()
     env.observe()
     oa = np.zeros((N, 2, 7, 2), np.int32)
-    for t in range(60):
+    for t in range(BOTWISE):
         env.scripted_actions(pa, 0)
         a = env.scripted_actions(pb, 1)
         ora.scripted_actions(P[pa], 0, o_obs, oa); ora.scripted_actions(P[pb], 1, o_obs, oa)
@@ -69,6 +71,6 @@ for c in range(first, first + count):
     assert all(np.array_equal(s[k], os_[k]) for k in ("groups", "nodes", "health", "env")), ("fused bots state", c, pa, pb)
     assert np.array_equal(env._actions.cpu().numpy(), oa), ("fused bots orders", c, pa, pb)
     env.close()
-    if c % 10 == 0:
+    if c % 10 == 0 or ENVS > 4096:
         print("config", c, "ok", flush=True)
-print("soak ok: %d random configurations" % count)
+print("soak ok: %d random configurations, %d games each" % (count, ENVS))
