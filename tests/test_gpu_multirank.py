@@ -8,7 +8,7 @@ Transports of the same child program:
   gloo, 2 ranks on GPU 0          runs on every box (the collective on host copies)
   nccl (= RCCL), 1 rank           runs on every box: process-group, device buffers and the RCCL launch of the gather, nothing on the wire
   evg_gather_returns, 1 rank      runs on every box: RCCL through the C-ABI (no torch.distributed), one rank; one rank per GPU like the nccl form below
-  nccl, one rank per visible GPU  needs >= 2 GPUs (xGMI); BASELINE config 4 at its full size (8 x 65 536) when 8 are visible.  SKIPPED on the
+  nccl, one rank per visible GPU  needs >= 2 GPUs (xGMI); at most 4 ranks unless EVG_TEST_MAX_RANKS=8 (then BASELINE config 4 at its full size).  SKIPPED on the
                                   one-GPU boxes this repository has been developed on: RCCL has not carried a row between two GPUs in any
                                   round, and this is the test that checks it the day a multi-GPU box runs the suite."""
 import os
@@ -96,6 +96,13 @@ def _gpus():
     return torch.cuda.device_count()          # (counting devices does not initialise the GPU)
 
 
+def _ranks():
+    """One rank per visible GPU, at most 4 unless EVG_TEST_MAX_RANKS says otherwise: the GPU boxes of this pool allow six processes of one user on the GPUs
+    at once (ranks + this pytest process), and a run that exceeds it is killed as a whole.  EVG_TEST_MAX_RANKS=8 on an 8-GPU node without that guard runs
+    BASELINE config 4 at its full size."""
+    return min(_gpus(), int(os.environ.get("EVG_TEST_MAX_RANKS", "4")))
+
+
 def _run_ranks(tmp_path, oracle_mod, backend, world, ndev, total, seed=20261005, steps=170):
     import everglades_amd as evg
     script = tmp_path / "rank_child.py"
@@ -156,9 +163,9 @@ def test_one_rank_over_rccl_vs_oracle(tmp_path, oracle_mod):
                     reason="needs >= 2 GPUs: one rank per GPU over RCCL / xGMI (this box has %d); the gloo and one-rank RCCL forms of the same program ran "
                            "instead" % _gpus())
 def test_one_rank_per_gpu_over_rccl_vs_oracle(tmp_path, oracle_mod):
-    """One rank per visible GPU (at most 8), backend nccl = RCCL over xGMI.  8 GPUs: BASELINE config 4 at its full size, 8 x 65 536 envs;
-    fewer: uneven shards of about 20 000 envs."""
-    world = min(_gpus(), 8)
+    """One rank per visible GPU (_ranks(): at most 4 by default), backend nccl = RCCL over xGMI.  8 ranks: BASELINE config 4 at its full size,
+    8 x 65 536 envs; fewer: uneven shards of about 20 000 envs."""
+    world = _ranks()
     total = 8 * 65536 if world == 8 else world * 20000 + 3
     parts, g = _run_ranks(tmp_path, oracle_mod, "nccl", world=world, ndev=world, total=total)
     assert str(g["backend"]) == "nccl" and sorted(int(p["device"]) for p in parts) == list(range(world))
@@ -172,8 +179,8 @@ def test_one_rank_over_the_abis_own_rccl_gather_vs_oracle(tmp_path, oracle_mod):
 
 @pytest.mark.skipif(_gpus() < 2, reason="needs >= 2 GPUs: one rank per GPU over RCCL / xGMI (this box has %d)" % _gpus())
 def test_one_rank_per_gpu_over_the_abis_own_rccl_gather_vs_oracle(tmp_path, oracle_mod):
-    """the same through evg_gather_returns, one rank per visible GPU (at most 8): what a consumer without torch.distributed runs"""
-    world = min(_gpus(), 8)
+    """the same through evg_gather_returns, one rank per visible GPU (_ranks()): what a consumer without torch.distributed runs"""
+    world = _ranks()
     total = 8 * 65536 if world == 8 else world * 20000 + 3
     parts, g = _run_ranks(tmp_path, oracle_mod, "evg", world=world, ndev=world, total=total)
     assert str(g["backend"]) == "evg_gather_returns" and sorted(int(p["device"]) for p in parts) == list(range(world))
