@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak (not a test): HIP against the oracle on MANY random configurations (oracle/custom_configs.random_config), every launch form.
-usage (on the GPU box): python tools/random_tables_soak.py [first] [count] [envs]     (envs > 4096: the two-lane kernels; fewer stepwise turns)"""
+usage (on the GPU box): python tools/random_tables_soak.py [first] [count] [envs]     (envs > 4096: fewer stepwise turns; persistent launches run the four-lane kernel for 2 / 3
+wavefronts per SIMD up to 32 768 / 49 152 envs and the two-lane kernel above)"""
 import json, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
